@@ -1,0 +1,220 @@
+/*
+ * vfsx.h -- C ABI of the MI355X-native exact-search engine that replaces the
+ * linear-search path of RaulMoldes/VFS (Ranker::search -> exact_search ->
+ * calculate_distance + sort/truncate top-k).
+ *
+ * The reference has no FFI/plugin boundary of its own (no `extern "C"`, no
+ * `unsafe`).  The seam this ABI replaces is the Rust method
+ *
+ *   Ranker::search(&mut self, query: &VFSVector, num_vectors_per_iteration: usize,
+ *                  result_limit: Option<usize>, manager: &mut VFSManager)
+ *       -> io::Result<Vec<(u64, f32)>>                    vfs/src/vfs/rank.rs:90-105
+ *
+ * and the data feed it pulls from, VFSManager::load_batch
+ * (vfs/src/vfs/storage_manager.rs:166-217).  Each entry point below cites the
+ * reference lines it stands in for.  All citations are relative to the reference
+ * repository root.
+ *
+ * Conventions
+ *   - plain C types only; caller owns every host buffer, the library owns all
+ *     device memory;
+ *   - every function returns VFSX_OK (0) or a negative vfsx_status; it never
+ *     unwinds or aborts across the ABI (the reference panics instead:
+ *     rank.rs:31,151,273-275); vfsx_last_error() gives the message (thread-local);
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point fails with VFSX_ERR_NO_DEVICE;
+ *   - one search at a time per corpus handle (the reference serialises every
+ *     request behind one mutex: vfs/src/main.rs:49, tcp.rs:367).
+ */
+#ifndef VFSX_H
+#define VFSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error classes mirror VFSError (vfs/src/vfs/err.rs:10-16) and the status table
+ * at vfs/src/vfs/tcp.rs:330-348. */
+typedef enum vfsx_status {
+    VFSX_OK = 0,
+    VFSX_ERR_IO = -1,             /* VFSError::IoError            -> HTTP 500 */
+    VFSX_ERR_MEMTABLE = -2,       /* VFSError::MemtableError      -> HTTP 500 */
+    VFSX_ERR_INVALID_VECTOR = -3, /* VFSError::InvalidVector      -> HTTP 400 */
+    VFSX_ERR_ID_GENERATION = -4,  /* VFSError::IdGenerationError  -> HTTP 500 */
+    VFSX_ERR_SERIALIZATION = -5,  /* VFSError::SerializationError -> HTTP 422 */
+    VFSX_ERR_INTERNAL = -6,       /* HIP/runtime failure          -> HTTP 500 */
+    VFSX_ERR_NO_DEVICE = -7       /* no gfx950 device / HIP extension unusable */
+} vfsx_status;
+
+/* Storage dtype of a corpus: VFSVector::Dense / VFSVector::Quantized
+ * (vfs/src/vfs/vector.rs:39-43). */
+typedef enum vfsx_dtype {
+    VFSX_F32 = 0, /* Vector { vector: Vec<f32> }                     vector.rs:21-25 */
+    VFSX_I8 = 1   /* QuantizedVector { vector: Vec<i8>, scale_factor } vector.rs:30-35 */
+} vfsx_dtype;
+
+/* DistanceMethod, in the reference's declaration order (rank.rs:67-72).
+ * SIMD_* are arithmetically identical to the scalar variants (ordered reduce_sum,
+ * rank.rs:25-26,46-48); unlike the reference they accept any dimension
+ * (the reference panics unless d is one of 2,4,8,16,32,64: rank.rs:31,303,307). */
+typedef enum vfsx_metric {
+    VFSX_EUCLIDEAN = 0,
+    VFSX_COSINE = 1,
+    VFSX_SIMD_EUCLIDEAN = 2,
+    VFSX_SIMD_COSINE = 3
+} vfsx_metric;
+
+/* One ranked hit as produced on the device.  `row` is the global scan position
+ * (row_base + local row): the reference's tie-break is (distance asc, first-seen
+ * scan position asc) (rank.rs:170, stable sort), so the position travels with the
+ * distance through every merge stage, including the cross-GPU one. */
+typedef struct vfsx_hit {
+    float dist;    /* the f32 the reference would put in the (u64, f32) tuple */
+    uint32_t flags; /* bit 0: valid */
+    uint64_t row;  /* global scan position */
+    uint64_t id;   /* VFSVector::id() (vector.rs:163-168) */
+} vfsx_hit;
+
+typedef struct vfsx_corpus vfsx_corpus;
+
+/* ---- runtime ---------------------------------------------------------------- */
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int vfsx_device_count(void);
+
+/* Message of the last failure on this thread ("" if none). */
+const char *vfsx_last_error(void);
+
+/* Library / layout version string, e.g. "vfsx 0.1 gfx950 rb64". */
+const char *vfsx_version(void);
+
+/* ---- corpus (replaces VFSManager as the thing the scan reads) ---------------- */
+
+/*
+ * Creates an empty device-resident corpus on HIP device `device`.
+ *   dim            vector dimension (ServerState::vector_dimension, tcp.rs:60-63); > 0
+ *   dtype          VFSX_F32 or VFSX_I8
+ *   scale          QuantizedVector::scale_factor (vector.rs:33); the store always uses
+ *                  127.0 (vector.rs:188).  Ignored for VFSX_F32.
+ *   capacity_rows  rows to reserve in HBM up front (grows by doubling when exceeded)
+ * Rows are kept in scan order = insertion order = ascending id
+ * (storage_manager.rs:139-157: flush order).  Returns NULL on failure.
+ */
+vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t capacity_rows,
+                                int device);
+
+void vfsx_corpus_destroy(vfsx_corpus *c);
+
+/*
+ * Appends `n` rows (row-major, `dim` elements each, of the corpus dtype) in scan
+ * order.  Stands in for the records VFSManager::load_batch would yield
+ * (storage_manager.rs:166-217): for VFSX_I8 the bytes are QuantizedVector::vector
+ * and are dequantized on read exactly as storage_manager.rs:202-210 does.
+ * `ids` NULL => ids continue 1,2,3.. (storage_manager.rs:76,126-130).
+ * Host rows are staged through pinned double buffers and copied with
+ * hipMemcpyAsync, then laid out on the device ("HBM layout").
+ */
+int vfsx_corpus_append(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n);
+
+/*
+ * VFSX_I8 corpora only: appends f32 rows, quantizing them on the device with the
+ * store's rule  q = (v * scale).round() as i8  (Vector::quantize(Some(127.0)),
+ * vector.rs:94-108,188; flush path storage_manager.rs:139-157).
+ */
+int vfsx_corpus_append_quantize(vfsx_corpus *c, const float *rows, const uint64_t *ids,
+                                uint64_t n);
+
+/* Number of rows currently searchable. */
+uint64_t vfsx_corpus_rows(const vfsx_corpus *c);
+uint32_t vfsx_corpus_dim(const vfsx_corpus *c);
+int vfsx_corpus_dtype(const vfsx_corpus *c);
+
+/*
+ * Global scan position of this corpus' row 0 (default 0).  Used when the vector
+ * set is row-sharded over several GPUs: shard g holds a contiguous range, so
+ * (row_base + local row) order equals the reference's scan order.
+ */
+int vfsx_corpus_set_row_base(vfsx_corpus *c, uint64_t row_base);
+
+/*
+ * Copies rows back as f32 (as_f32_vec semantics, vector.rs:281-290: an int8 row
+ * comes back dequantized).  `rows` are LOCAL row indices.  Used for result
+ * hydration (get_vector_by_id, storage_manager.rs:235-296; tcp.rs:408-427).
+ */
+int vfsx_corpus_get_rows_f32(vfsx_corpus *c, const uint64_t *rows, uint64_t n, float *out);
+
+/* Raw stored bytes of LOCAL rows (f32 or i8 per the corpus dtype), row-major. */
+int vfsx_corpus_get_rows_raw(vfsx_corpus *c, const uint64_t *rows, uint64_t n, void *out);
+
+/* id of LOCAL rows. */
+int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64_t *out);
+
+/*
+ * Benchmark utility (no reference counterpart): fills the corpus on the device
+ * with `n` rows of the counter-based synthetic generator described in DESIGN.md
+ * (element (i,j) <- splitmix64(seed + (row0+i)*dim + j), uniform in [-1,1); an
+ * int8 corpus stores quantize(value, scale)).  The corpus must be empty; ids are
+ * id0, id0+1, ...
+ */
+int vfsx_corpus_fill_synthetic(vfsx_corpus *c, uint64_t seed, uint64_t row0, uint64_t n,
+                               uint64_t id0);
+
+/* ---- search (replaces Ranker::search / exact_search, rank.rs:90-186) --------- */
+
+/*
+ * Exact top-k of each of `nq` f32 queries (row-major, `dim` each; the reference's
+ * query is always Dense f32: tcp.rs:377-379) against the corpus.
+ *   k        result_limit.unwrap_or(5) (rank.rs:129); 1..VFSX_MAX_K
+ *   metric   vfsx_metric
+ * Outputs (host): out_ids[nq*k], out_dist[nq*k], ranked ascending by
+ * (distance, scan position); out_count[q] = min(k, rows) hits are valid for query q
+ * (rank.rs:172: fewer than `limit` only when the corpus is smaller).
+ * num_vectors_per_iteration (rank.rs:91) has no counterpart: the reference's result
+ * does not depend on it, except that 0 yields an empty result, which
+ * the host wrappers reproduce.
+ */
+int vfsx_search(vfsx_corpus *c, const float *queries, uint32_t nq, uint32_t k, int metric,
+                uint64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+/*
+ * Same search with device-resident inputs and outputs, enqueued on HIP stream
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream) without any
+ * host synchronisation:
+ *   d_queries  device, nq*dim f32
+ *   d_hits     device, nq*k vfsx_hit; entries past the valid count have flags = 0
+ * Used by the multi-GPU path (local top-k -> all-gather -> vfsx_merge_hits_device)
+ * and by the benchmark (inputs already resident in HBM).
+ */
+int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k,
+                       int metric, vfsx_hit *d_hits, void *stream);
+
+/*
+ * Cross-shard merge (no reference counterpart): for each of nq
+ * queries, d_in holds n_lists ranked lists of k hits laid out [list][query][k]
+ * (the layout an all-gather of every rank's [query][k] block produces).  Writes
+ * the k best by (distance, row) to d_out[nq*k].  Device pointers, enqueued on `stream`.
+ */
+int vfsx_merge_hits_device(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
+                           vfsx_hit *d_out, int device, void *stream);
+
+/* Host version of the same merge (pure host logic; needs no GPU). */
+int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint32_t k,
+                         vfsx_hit *out);
+
+/*
+ * Profiling aid: when enabled, vfsx_search / vfsx_search_device bracket the scan
+ * kernel with HIP events on the stream it is launched on; vfsx_corpus_scan_time_ms
+ * returns the accumulated kernel milliseconds and launch count since the last reset
+ * (synchronises on the last event).
+ */
+int vfsx_corpus_set_profiling(vfsx_corpus *c, int enabled);
+int vfsx_corpus_scan_time_ms(vfsx_corpus *c, double *total_ms, uint64_t *launches, int reset);
+
+#define VFSX_MAX_K 1024u
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFSX_H */

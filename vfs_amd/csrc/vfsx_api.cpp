@@ -1,0 +1,690 @@
+// vfsx_api.cpp -- the C ABI of include/vfsx.h: corpus residency in HBM, the pinned
+// double-buffered ingest pipeline, search orchestration and error mapping.
+// There is deliberately no CPU compute path in this file: every search runs the
+// HIP kernels of vfsx_kernels.hip or fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vfsx_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct VfsxError : std::runtime_error {
+    int code;
+    VfsxError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] void fail(int code, const std::string &msg) { throw VfsxError(code, msg); }
+
+void hip_check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) {
+        int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+                       ? VFSX_ERR_NO_DEVICE
+                       : VFSX_ERR_INTERNAL;
+        fail(code, std::string(what) + ": " + hipGetErrorString(e));
+    }
+}
+#define HIP_CHECK(x) hip_check((x), #x)
+
+template <typename F>
+int guarded(F &&f)
+{
+    try {
+        g_last_error.clear();
+        f();
+        return VFSX_OK;
+    } catch (const VfsxError &e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_last_error = "out of host memory";
+        return VFSX_ERR_INTERNAL;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return VFSX_ERR_INTERNAL;
+    } catch (...) {
+        g_last_error = "unknown failure";
+        return VFSX_ERR_INTERNAL;
+    }
+}
+
+uint64_t env_u64(const char *name, uint64_t dflt)
+{
+    const char *v = std::getenv(name);
+    if (!v || !*v)
+        return dflt;
+    char *end = nullptr;
+    unsigned long long x = std::strtoull(v, &end, 10);
+    return (end && *end == 0) ? (uint64_t)x : dflt;
+}
+
+int device_count_quiet()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+template <typename T>
+struct DeviceBuf {
+    T *p = nullptr;
+    size_t n = 0; // elements
+    void reserve(size_t want)
+    {
+        if (want <= n)
+            return;
+        if (p)
+            HIP_CHECK(hipFree(p));
+        p = nullptr;
+        n = 0;
+        HIP_CHECK(hipMalloc((void **)&p, want * sizeof(T)));
+        n = want;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+} // namespace
+
+struct vfsx_corpus {
+    int device = 0;
+    uint32_t dim = 0;
+    int dtype = VFSX_F32;
+    float scale = 127.0f;
+    uint32_t epc = 4;      // elements per 16-byte chunk
+    uint32_t d_chunks = 0; // chunks per row
+    uint64_t capacity = 0; // rows reserved (multiple of 64)
+    uint64_t n_rows = 0;
+    uint64_t row_base = 0;
+    uint64_t id_base = 1;  // implicit ids: id_base + local row (storage_manager.rs:76)
+    bool explicit_ids = false;
+    std::vector<uint64_t> ids_host; // only when explicit_ids
+
+    uint4 *d_corpus = nullptr;
+    float *d_norms = nullptr;
+    uint64_t *d_ids = nullptr;
+    float *d_lut = nullptr;
+
+    hipStream_t stream = nullptr; // ingest + host-API searches
+    // ingest staging (pinned host + device), double buffered
+    size_t stage_bytes = 0;
+    void *h_stage[2] = {nullptr, nullptr};
+    void *d_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+
+    // search workspace
+    DeviceBuf<uint64_t> lists;
+    DeviceBuf<float> q_in, q_pad, q_norms;
+    DeviceBuf<vfsx_hit> hits;
+    DeviceBuf<uint64_t> row_idx;
+    DeviceBuf<uint8_t> row_out;
+    uint32_t max_blocks = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0;
+
+    size_t block_bytes() const { return (size_t)d_chunks * 1024u; }
+    size_t corpus_bytes(uint64_t rows) const { return (size_t)(rows / 64u) * block_bytes(); }
+};
+
+namespace {
+
+using vfsx::ScanArgs;
+using vfsx::SelectArgs;
+
+void use_device(const vfsx_corpus *c) { HIP_CHECK(hipSetDevice(c->device)); }
+
+uint64_t round_up64(uint64_t x) { return (x + 63u) / 64u * 64u; }
+
+void reserve_rows(vfsx_corpus *c, uint64_t want_rows)
+{
+    if (want_rows <= c->capacity)
+        return;
+    if (want_rows > 0xfffffffeull - 64u)
+        fail(VFSX_ERR_MEMTABLE, "corpus shard limited to 2^32-66 rows per device");
+    uint64_t cap = std::max<uint64_t>(round_up64(want_rows), std::min<uint64_t>(c->capacity * 2, 0xffffff00ull));
+    cap = std::max<uint64_t>(cap, 64);
+    uint4 *nc = nullptr;
+    float *nn = nullptr;
+    uint64_t *ni = nullptr;
+    HIP_CHECK(hipMalloc((void **)&nc, c->corpus_bytes(cap)));
+    HIP_CHECK(hipMalloc((void **)&nn, cap * sizeof(float)));
+    if (c->explicit_ids)
+        HIP_CHECK(hipMalloc((void **)&ni, cap * sizeof(uint64_t)));
+    // rows past n_rows are read by the scan but masked (row < n_rows): any bytes will do
+    HIP_CHECK(hipMemsetAsync(nn, 0, cap * sizeof(float), c->stream));
+    if (c->n_rows) {
+        HIP_CHECK(hipMemcpyAsync(nc, c->d_corpus, c->corpus_bytes(round_up64(c->n_rows)),
+                                 hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(nn, c->d_norms, c->n_rows * sizeof(float), hipMemcpyDeviceToDevice,
+                                 c->stream));
+        if (c->explicit_ids && c->d_ids)
+            HIP_CHECK(hipMemcpyAsync(ni, c->d_ids, c->n_rows * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                     c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_corpus)
+        HIP_CHECK(hipFree(c->d_corpus));
+    if (c->d_norms)
+        HIP_CHECK(hipFree(c->d_norms));
+    if (c->d_ids)
+        HIP_CHECK(hipFree(c->d_ids));
+    c->d_corpus = nc;
+    c->d_norms = nn;
+    c->d_ids = ni;
+    c->capacity = cap;
+}
+
+void ensure_staging(vfsx_corpus *c)
+{
+    if (c->h_stage[0])
+        return;
+    size_t bytes = (size_t)env_u64("VFSX_STAGE_MB", 32) << 20;
+    size_t row_bytes = (size_t)c->dim * sizeof(float); // widest source row (f32)
+    bytes = std::max(bytes, row_bytes);
+    for (int i = 0; i < 2; ++i) {
+        HIP_CHECK(hipHostMalloc(&c->h_stage[i], bytes, hipHostMallocDefault));
+        HIP_CHECK(hipMalloc(&c->d_stage[i], bytes));
+        HIP_CHECK(hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming));
+    }
+    c->stage_bytes = bytes;
+}
+
+// make ids explicit: materialise the implicit run for rows already stored
+void make_ids_explicit(vfsx_corpus *c)
+{
+    if (c->explicit_ids)
+        return;
+    c->ids_host.resize(c->n_rows);
+    for (uint64_t r = 0; r < c->n_rows; ++r)
+        c->ids_host[r] = c->id_base + r;
+    c->explicit_ids = true;
+    HIP_CHECK(hipMalloc((void **)&c->d_ids, std::max<uint64_t>(c->capacity, 64) * sizeof(uint64_t)));
+    if (c->n_rows)
+        HIP_CHECK(hipMemcpy(c->d_ids, c->ids_host.data(), c->n_rows * sizeof(uint64_t), hipMemcpyHostToDevice));
+}
+
+// mode 0: f32 rows -> f32 corpus, 1: i8 -> i8, 2: f32 -> i8 (quantize on device)
+void append_impl(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n, int mode)
+{
+    if (n == 0)
+        return;
+    if (!rows)
+        fail(VFSX_ERR_INVALID_VECTOR, "Vector data cannot be empty"); // storage_manager.rs:319-321
+    use_device(c);
+    if (ids)
+        make_ids_explicit(c);
+    reserve_rows(c, c->n_rows + n);
+    ensure_staging(c);
+    const size_t src_elem = (mode == 1) ? 1 : 4;
+    const size_t src_row = (size_t)c->dim * src_elem;
+    const uint64_t rows_per_batch = std::max<uint64_t>(1, c->stage_bytes / src_row);
+    const uint8_t *src = (const uint8_t *)rows;
+    uint64_t done = 0;
+    int buf = 0;
+    while (done < n) {
+        const uint64_t take = std::min(rows_per_batch, n - done);
+        // the previous kernel that read d_stage[buf] (and the copy out of h_stage[buf]) must be over
+        HIP_CHECK(hipEventSynchronize(c->stage_done[buf]));
+        std::memcpy(c->h_stage[buf], src + done * src_row, take * src_row);
+        HIP_CHECK(hipMemcpyAsync(c->d_stage[buf], c->h_stage[buf], take * src_row, hipMemcpyHostToDevice,
+                                 c->stream));
+        HIP_CHECK(vfsx::launch_ingest(mode, c->d_stage[buf], take, c->dim, c->d_corpus, c->d_chunks,
+                                      c->n_rows + done, c->scale, c->stream));
+        HIP_CHECK(hipEventRecord(c->stage_done[buf], c->stream));
+        done += take;
+        buf ^= 1;
+    }
+    HIP_CHECK(vfsx::launch_row_norms(c->dtype, c->d_corpus, c->d_chunks, c->d_lut, c->n_rows, n, c->d_norms,
+                                     c->stream));
+    if (c->explicit_ids) {
+        const size_t old = c->ids_host.size();
+        c->ids_host.resize(old + n);
+        for (uint64_t i = 0; i < n; ++i)
+            c->ids_host[old + i] = ids ? ids[i] : (c->id_base + c->n_rows + i);
+        HIP_CHECK(hipMemcpyAsync(c->d_ids + c->n_rows, c->ids_host.data() + old, n * sizeof(uint64_t),
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->n_rows += n;
+}
+
+bool is_cosine(int metric) { return metric == VFSX_COSINE || metric == VFSX_SIMD_COSINE; }
+
+void prof_begin(vfsx_corpus *c, hipStream_t s, size_t &slot)
+{
+    if (!c->profiling)
+        return;
+    if (c->prof_used == c->prof_events.size()) {
+        hipEvent_t a, b;
+        HIP_CHECK(hipEventCreate(&a));
+        HIP_CHECK(hipEventCreate(&b));
+        c->prof_events.push_back({a, b});
+    }
+    slot = c->prof_used++;
+    HIP_CHECK(hipEventRecord(c->prof_events[slot].first, s));
+}
+
+void prof_end(vfsx_corpus *c, hipStream_t s, size_t slot)
+{
+    if (!c->profiling)
+        return;
+    HIP_CHECK(hipEventRecord(c->prof_events[slot].second, s));
+}
+
+void prof_collect(vfsx_corpus *c)
+{
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        HIP_CHECK(hipEventSynchronize(c->prof_events[i].second));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+        c->prof_ms += ms;
+        c->prof_launches += 1;
+    }
+    c->prof_used = 0;
+}
+
+// enqueue the whole search on `s`; no host synchronisation
+void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                        vfsx_hit *d_hits, hipStream_t s)
+{
+    if (metric < VFSX_EUCLIDEAN || metric > VFSX_SIMD_COSINE)
+        fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
+    if (k == 0 || k > VFSX_MAX_K)
+        fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
+    if (nq == 0)
+        return;
+    if (!d_queries || !d_hits)
+        fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
+    use_device(c);
+    if (c->prof_used > 4096)
+        prof_collect(c);
+
+    const uint32_t q_stride_pad = c->d_chunks * c->epc;
+    const bool need_pad = (q_stride_pad != c->dim);
+    const bool cosine = is_cosine(metric);
+    const float *q_ptr = d_queries;
+    uint32_t q_stride = c->dim;
+    if (need_pad || cosine) {
+        if (need_pad)
+            c->q_pad.reserve((size_t)nq * q_stride_pad);
+        if (cosine)
+            c->q_norms.reserve(nq);
+        HIP_CHECK(vfsx::launch_query_prep(d_queries, nq, c->dim, need_pad ? c->q_pad.p : nullptr, q_stride_pad,
+                                          cosine ? c->q_norms.p : nullptr, s));
+        if (need_pad) {
+            q_ptr = c->q_pad.p;
+            q_stride = q_stride_pad;
+        }
+    }
+
+    const uint32_t n_rowblocks = (uint32_t)((c->n_rows + 63u) / 64u);
+    uint32_t grid_x = std::min<uint32_t>((n_rowblocks + 3u) / 4u, c->max_blocks);
+    // queries per launch: bounded by gridDim.y and by a 256 MiB list workspace
+    uint32_t q_per_launch = nq;
+    if (grid_x) {
+        const uint64_t per_q = (uint64_t)grid_x * k * sizeof(uint64_t);
+        q_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / per_q));
+        q_per_launch = std::min<uint32_t>(q_per_launch, 32768u);
+        c->lists.reserve((size_t)q_per_launch * grid_x * k);
+    }
+    for (uint32_t q0 = 0; q0 < nq; q0 += q_per_launch) {
+        const uint32_t qn = std::min(q_per_launch, nq - q0);
+        if (grid_x) {
+            ScanArgs a{};
+            a.corpus = c->d_corpus;
+            a.row_norms = c->d_norms;
+            a.queries = q_ptr + (size_t)q0 * q_stride;
+            a.q_norms = cosine ? c->q_norms.p + q0 : nullptr;
+            a.lut = c->d_lut;
+            a.lists = c->lists.p;
+            a.n_rows = (uint32_t)c->n_rows;
+            a.d_chunks = c->d_chunks;
+            a.n_rowblocks = n_rowblocks;
+            a.q_stride = q_stride;
+            a.k = k;
+            a.n_lists = grid_x;
+            size_t slot = 0;
+            prof_begin(c, s, slot);
+            HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, s));
+            prof_end(c, s, slot);
+        }
+        SelectArgs sa{};
+        sa.lists = c->lists.p;
+        sa.ids = c->explicit_ids ? c->d_ids : nullptr;
+        sa.out = d_hits + (size_t)q0 * k;
+        sa.row_base = c->row_base;
+        sa.id_base = c->id_base;
+        sa.n_lists = grid_x;
+        sa.k = k;
+        HIP_CHECK(vfsx::launch_select(sa, qn, s));
+    }
+}
+
+vfsx_corpus *checked(vfsx_corpus *c)
+{
+    if (!c)
+        fail(VFSX_ERR_INVALID_VECTOR, "null corpus handle");
+    return c;
+}
+
+void fetch_rows(vfsx_corpus *c, const uint64_t *rows, uint64_t n, int as_f32, void *out)
+{
+    if (n == 0)
+        return;
+    if (!rows || !out)
+        fail(VFSX_ERR_INVALID_VECTOR, "null buffer");
+    for (uint64_t i = 0; i < n; ++i)
+        if (rows[i] >= c->n_rows)
+            fail(VFSX_ERR_INVALID_VECTOR, "row index out of range");
+    use_device(c);
+    const size_t elem = (c->dtype == VFSX_I8 && !as_f32) ? 1 : 4;
+    c->row_idx.reserve(n);
+    c->row_out.reserve((size_t)n * c->dim * elem);
+    HIP_CHECK(hipMemcpyAsync(c->row_idx.p, rows, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(vfsx::launch_get_rows(c->dtype, c->d_corpus, c->dim, c->d_chunks, c->d_lut, c->row_idx.p, n,
+                                    as_f32, c->row_out.p, c->stream));
+    HIP_CHECK(hipMemcpyAsync(out, c->row_out.p, (size_t)n * c->dim * elem, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+} // namespace
+
+extern "C" {
+
+int vfsx_device_count(void) { return device_count_quiet(); }
+
+const char *vfsx_last_error(void) { return g_last_error.c_str(); }
+
+const char *vfsx_version(void) { return "vfsx 0.1 gfx950 rb64"; }
+
+vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t capacity_rows, int device)
+{
+    vfsx_corpus *c = nullptr;
+    int rc = guarded([&] {
+        if (dim == 0)
+            fail(VFSX_ERR_INVALID_VECTOR, "Vector data cannot be empty"); // storage_manager.rs:319
+        if (dtype != VFSX_F32 && dtype != VFSX_I8)
+            fail(VFSX_ERR_INVALID_VECTOR, "unknown corpus dtype");
+        if (dtype == VFSX_I8 && !(scale == scale) )
+            fail(VFSX_ERR_INVALID_VECTOR, "scale_factor must not be NaN");
+        int ndev = device_count_quiet();
+        if (ndev <= 0)
+            fail(VFSX_ERR_NO_DEVICE, "no HIP device visible: vfsx has no CPU fallback");
+        if (device < 0 || device >= ndev)
+            fail(VFSX_ERR_NO_DEVICE, "HIP device index out of range");
+        HIP_CHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("VFSX_ALLOW_ANY_ARCH"))
+            fail(VFSX_ERR_NO_DEVICE, std::string("vfsx is built for gfx950 only, device is ") + prop.gcnArchName);
+        c = new vfsx_corpus();
+        c->device = device;
+        c->dim = dim;
+        c->dtype = dtype;
+        c->scale = dtype == VFSX_I8 ? scale : 1.0f;
+        c->epc = vfsx::elems_per_chunk(dtype);
+        c->d_chunks = (dim + c->epc - 1) / c->epc;
+        c->max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)env_u64("VFSX_BLOCKS_PER_CU", 8);
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
+        if (dtype == VFSX_I8)
+            HIP_CHECK(vfsx::launch_lut(c->scale, c->d_lut, c->stream));
+        else
+            HIP_CHECK(hipMemsetAsync(c->d_lut, 0, 256 * sizeof(float), c->stream));
+        reserve_rows(c, std::max<uint64_t>(capacity_rows, 64));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    });
+    if (rc != VFSX_OK) {
+        if (c)
+            vfsx_corpus_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void vfsx_corpus_destroy(vfsx_corpus *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    for (auto &pe : c->prof_events) {
+        (void)hipEventDestroy(pe.first);
+        (void)hipEventDestroy(pe.second);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_stage[i])
+            (void)hipHostFree(c->h_stage[i]);
+        if (c->d_stage[i])
+            (void)hipFree(c->d_stage[i]);
+        if (c->stage_done[i])
+            (void)hipEventDestroy(c->stage_done[i]);
+    }
+    c->lists.release();
+    c->q_in.release();
+    c->q_pad.release();
+    c->q_norms.release();
+    c->hits.release();
+    c->row_idx.release();
+    c->row_out.release();
+    if (c->d_corpus)
+        (void)hipFree(c->d_corpus);
+    if (c->d_norms)
+        (void)hipFree(c->d_norms);
+    if (c->d_ids)
+        (void)hipFree(c->d_ids);
+    if (c->d_lut)
+        (void)hipFree(c->d_lut);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vfsx_corpus_append(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n)
+{
+    return guarded([&] {
+        checked(c);
+        append_impl(c, rows, ids, n, c->dtype == VFSX_I8 ? 1 : 0);
+    });
+}
+
+int vfsx_corpus_append_quantize(vfsx_corpus *c, const float *rows, const uint64_t *ids, uint64_t n)
+{
+    return guarded([&] {
+        checked(c);
+        if (c->dtype != VFSX_I8) // VFSVector::quantize on a non-quantizing store is never called
+            fail(VFSX_ERR_INVALID_VECTOR, "append_quantize needs a VFSX_I8 corpus");
+        append_impl(c, rows, ids, n, 2);
+    });
+}
+
+uint64_t vfsx_corpus_rows(const vfsx_corpus *c) { return c ? c->n_rows : 0; }
+uint32_t vfsx_corpus_dim(const vfsx_corpus *c) { return c ? c->dim : 0; }
+int vfsx_corpus_dtype(const vfsx_corpus *c) { return c ? c->dtype : -1; }
+
+int vfsx_corpus_set_row_base(vfsx_corpus *c, uint64_t row_base)
+{
+    return guarded([&] {
+        checked(c);
+        c->row_base = row_base;
+    });
+}
+
+int vfsx_corpus_get_rows_f32(vfsx_corpus *c, const uint64_t *rows, uint64_t n, float *out)
+{
+    return guarded([&] { fetch_rows(checked(c), rows, n, 1, out); });
+}
+
+int vfsx_corpus_get_rows_raw(vfsx_corpus *c, const uint64_t *rows, uint64_t n, void *out)
+{
+    return guarded([&] { fetch_rows(checked(c), rows, n, 0, out); });
+}
+
+int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64_t *out)
+{
+    return guarded([&] {
+        checked(c);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (rows[i] >= c->n_rows)
+                fail(VFSX_ERR_INVALID_VECTOR, "row index out of range");
+            out[i] = c->explicit_ids ? c->ids_host[rows[i]] : c->id_base + rows[i];
+        }
+    });
+}
+
+int vfsx_corpus_fill_synthetic(vfsx_corpus *c, uint64_t seed, uint64_t row0, uint64_t n, uint64_t id0)
+{
+    return guarded([&] {
+        checked(c);
+        if (c->n_rows != 0)
+            fail(VFSX_ERR_MEMTABLE, "fill_synthetic needs an empty corpus");
+        if (n == 0)
+            return;
+        use_device(c);
+        reserve_rows(c, n);
+        // keep each launch's grid below 2^31 blocks
+        const uint64_t rows_per_launch = std::max<uint64_t>(64, ((1ull << 36) / ((uint64_t)c->d_chunks * 64u)) / 64u * 64u);
+        for (uint64_t r = 0; r < n; r += rows_per_launch) {
+            const uint64_t take = std::min(rows_per_launch, n - r);
+            HIP_CHECK(vfsx::launch_fill_synthetic(c->dtype, c->d_corpus, c->dim, c->d_chunks, r, take, seed,
+                                                  row0 + r, c->scale, c->stream));
+        }
+        HIP_CHECK(vfsx::launch_row_norms(c->dtype, c->d_corpus, c->d_chunks, c->d_lut, 0, n, c->d_norms, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->id_base = id0;
+        c->n_rows = n;
+    });
+}
+
+int vfsx_search(vfsx_corpus *c, const float *queries, uint32_t nq, uint32_t k, int metric, uint64_t *out_ids,
+                float *out_dist, uint32_t *out_count)
+{
+    return guarded([&] {
+        checked(c);
+        if (nq == 0)
+            return;
+        if (!queries || !out_ids || !out_dist || !out_count)
+            fail(VFSX_ERR_INVALID_VECTOR, "null buffer");
+        if (k == 0 || k > VFSX_MAX_K)
+            fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
+        use_device(c);
+        c->q_in.reserve((size_t)nq * c->dim);
+        c->hits.reserve((size_t)nq * k);
+        HIP_CHECK(hipMemcpyAsync(c->q_in.p, queries, (size_t)nq * c->dim * sizeof(float), hipMemcpyHostToDevice,
+                                 c->stream));
+        search_device_impl(c, c->q_in.p, nq, k, metric, c->hits.p, c->stream);
+        std::vector<vfsx_hit> h((size_t)nq * k);
+        HIP_CHECK(hipMemcpyAsync(h.data(), c->hits.p, h.size() * sizeof(vfsx_hit), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (uint32_t q = 0; q < nq; ++q) {
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                const vfsx_hit &x = h[(size_t)q * k + j];
+                if (x.flags & 1u) {
+                    out_ids[(size_t)q * k + cnt] = x.id;
+                    out_dist[(size_t)q * k + cnt] = x.dist;
+                    ++cnt;
+                }
+            }
+            out_count[q] = cnt;
+        }
+    });
+}
+
+int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                       vfsx_hit *d_hits, void *stream)
+{
+    return guarded([&] { search_device_impl(checked(c), d_queries, nq, k, metric, d_hits, (hipStream_t)stream); });
+}
+
+int vfsx_merge_hits_device(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k, vfsx_hit *d_out,
+                           int device, void *stream)
+{
+    return guarded([&] {
+        if (!d_in || !d_out || n_lists == 0 || k == 0)
+            fail(VFSX_ERR_INVALID_VECTOR, "bad merge arguments");
+        if (nq == 0)
+            return;
+        if (device_count_quiet() <= 0)
+            fail(VFSX_ERR_NO_DEVICE, "no HIP device visible: vfsx has no CPU fallback");
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(vfsx::launch_merge_hits(d_in, n_lists, nq, k, d_out, (hipStream_t)stream));
+    });
+}
+
+int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint32_t k, vfsx_hit *out)
+{
+    return guarded([&] {
+        if (!in || !out || n_lists == 0 || k == 0)
+            fail(VFSX_ERR_INVALID_VECTOR, "bad merge arguments");
+        std::vector<vfsx_hit> tmp((size_t)n_lists * k);
+        for (uint32_t q = 0; q < nq; ++q) {
+            for (uint32_t l = 0; l < n_lists; ++l)
+                std::memcpy(&tmp[(size_t)l * k], &in[((size_t)l * nq + q) * k], k * sizeof(vfsx_hit));
+            std::stable_sort(tmp.begin(), tmp.end(), [](const vfsx_hit &a, const vfsx_hit &b) {
+                const uint32_t va = a.flags & 1u, vb = b.flags & 1u;
+                if (va != vb)
+                    return va > vb;
+                const uint32_t ka = vfsx::host_dist_key(a.dist), kb = vfsx::host_dist_key(b.dist);
+                if (ka != kb)
+                    return ka < kb;
+                return a.row < b.row;
+            });
+            std::memcpy(&out[(size_t)q * k], tmp.data(), k * sizeof(vfsx_hit));
+        }
+    });
+}
+
+int vfsx_corpus_set_profiling(vfsx_corpus *c, int enabled)
+{
+    return guarded([&] {
+        checked(c);
+        use_device(c);
+        if (!enabled)
+            prof_collect(c);
+        c->profiling = enabled != 0;
+    });
+}
+
+int vfsx_corpus_scan_time_ms(vfsx_corpus *c, double *total_ms, uint64_t *launches, int reset)
+{
+    return guarded([&] {
+        checked(c);
+        use_device(c);
+        prof_collect(c);
+        if (total_ms)
+            *total_ms = c->prof_ms;
+        if (launches)
+            *launches = c->prof_launches;
+        if (reset) {
+            c->prof_ms = 0.0;
+            c->prof_launches = 0;
+        }
+    });
+}
+
+} // extern "C"

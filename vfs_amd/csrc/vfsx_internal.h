@@ -1,0 +1,85 @@
+// vfsx_internal.h -- shared between the HIP kernels (vfsx_kernels.hip) and the
+// C-ABI host layer (vfsx_api.cpp).  Not installed; the public surface is include/vfsx.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vfsx.h"
+
+namespace vfsx {
+
+// ---- HBM layout ("rb64"): see DESIGN.md --------------------------------------
+// Rows are grouped in row-blocks of 64 (one wavefront: lane l owns row 64*b + l).
+// A row is cut into 16-byte chunks (4 f32 or 16 i8).  Chunk c of row-block b is the
+// 1 KiB span  [b*d_chunks + c] * 1024 .. +1024, holding lane 0..63's chunk c back to
+// back, so one global_load_dwordx4 per lane reads 1 KiB contiguous AND every lane
+// receives its own row's elements 4c..4c+3 (16c..16c+15) in index order.
+constexpr uint32_t kRowBlock = 64;
+constexpr uint32_t kChunkBytes = 16;
+constexpr uint64_t kSentinel = ~0ull;   // empty top-k slot
+constexpr uint32_t kMaxRegisterK = 64;  // k <= 64: the wave's list lives in registers
+
+inline uint32_t elems_per_chunk(int dtype) { return dtype == VFSX_I8 ? 16u : 4u; }
+
+struct ScanArgs {
+    const uint4 *corpus;    // rb64 layout
+    const float *row_norms; // [n_rows] sqrt(sum x^2), sequential order (cosine only)
+    const float *queries;   // [nq][q_stride] f32, zero padded to d_chunks*epc
+    const float *q_norms;   // [nq] (cosine only)
+    const float *lut;       // [256] f32 dequant table indexed by the raw byte (i8 only)
+    uint64_t *lists;        // out: [nq][n_lists][k] composite keys, ascending, kSentinel padded
+    uint32_t n_rows;
+    uint32_t d_chunks;
+    uint32_t n_rowblocks;
+    uint32_t q_stride;
+    uint32_t k;
+    uint32_t n_lists; // = gridDim.x (one list per workgroup)
+};
+
+struct SelectArgs {
+    const uint64_t *lists; // [nq][n_lists][k]
+    const uint64_t *ids;   // [n_rows] or nullptr (=> id_base + local row)
+    vfsx_hit *out;         // [nq][k]
+    uint64_t row_base;
+    uint64_t id_base;
+    uint32_t n_lists;
+    uint32_t k;
+};
+
+// launchers (vfsx_kernels.hip). All enqueue on `s` and return the launch status.
+hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x,
+                       hipStream_t s);
+hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s);
+hipError_t launch_query_prep(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
+                             uint32_t q_stride, float *d_q_norms, hipStream_t s);
+hipError_t launch_lut(float scale, float *d_lut, hipStream_t s);
+// staging (row-major, n rows of `dim` src elements) -> rb64 rows [row0, row0+n)
+//   mode 0: f32 -> f32   1: i8 -> i8   2: f32 -> i8 (quantize, vector.rs:94-108)
+hipError_t launch_ingest(int mode, const void *d_staging, uint64_t n, uint32_t dim, uint4 *corpus,
+                         uint32_t d_chunks, uint64_t row0, float scale, hipStream_t s);
+hipError_t launch_row_norms(int dtype, const uint4 *corpus, uint32_t d_chunks, const float *d_lut,
+                            uint64_t row0, uint64_t n, float *row_norms, hipStream_t s);
+hipError_t launch_fill_synthetic(int dtype, uint4 *corpus, uint32_t dim, uint32_t d_chunks,
+                                 uint64_t row0_local, uint64_t n, uint64_t seed, uint64_t synth_row0,
+                                 float scale, hipStream_t s);
+// gather LOCAL rows back to row-major; as_f32 != 0 dequantizes i8 through the LUT
+hipError_t launch_get_rows(int dtype, const uint4 *corpus, uint32_t dim, uint32_t d_chunks,
+                           const float *d_lut, const uint64_t *d_rows, uint64_t n, int as_f32,
+                           void *d_out, hipStream_t s);
+hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
+                             vfsx_hit *d_out, hipStream_t s);
+
+// host helpers shared with the host merge
+inline uint32_t host_dist_key(float d)
+{
+    uint32_t b;
+    __builtin_memcpy(&b, &d, 4);
+    if ((b & 0x7fffffffu) > 0x7f800000u)
+        return 0xffffffffu; // NaN sorts last
+    if (b == 0x80000000u)
+        b = 0; // -0.0 == +0.0 (partial_cmp)
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+} // namespace vfsx

@@ -1,0 +1,789 @@
+// vfsx_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the VFS Ranker
+// linear-search path.  Built with -ffp-contract=off: every f32 operation below is
+// one correctly-rounded IEEE-754 binary32 operation, in the reference's order
+// (vfs/src/vfs/rank.rs:271-300), so distances are bit-identical to the reference's
+// scalar (and ordered-reduce SIMD) arithmetic.
+//
+// Design (DESIGN.md has the long form):
+//   * the corpus sits in HBM in the "rb64" layout (vfsx_internal.h): one wavefront
+//     owns 64 rows, lane l accumulates row l strictly sequentially, and every
+//     global_load_dwordx4 of the wave still reads 1 KiB contiguous;
+//   * the query is wave-uniform -> scalar loads, SGPR operands;
+//   * top-k is fused: each wave keeps a sorted list of composite keys
+//     (monotone f32 key << 32 | local row) in registers (k <= 64) or LDS, and only
+//     touches it when a ballot says a lane beat the current k-th best;
+//   * one list per workgroup goes to HBM; a tiny select kernel merges them.
+#include <hip/hip_runtime.h>
+
+#include "vfsx_internal.h"
+
+// No FMA contraction anywhere in this file, whatever the command line says.
+#pragma clang fp contract(off)
+
+namespace vfsx {
+
+namespace {
+
+// One IEEE-754 binary32 operation each, round-to-nearest-even.  NOT the HIP
+// __f*_rn intrinsics: without OCML_BASIC_ROUNDED_OPERATIONS __fsqrt_rn is the
+// *native* (1 ulp) sqrt.  sqrtf and `/` are correctly rounded because hipcc's
+// -fhip-fp32-correctly-rounded-divide-sqrt is on by default (the Makefile also
+// passes it explicitly); tests/test_gpu_parity.py checks both bit-for-bit.
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float f_sqrt(float a) { return __builtin_sqrtf(a); }
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// ---- key <-> distance ---------------------------------------------------------
+// Monotone map of an f32 to a u32 so that u32 order == the reference's
+// partial_cmp order (rank.rs:170) for non-NaN values, with -0.0 == +0.0.
+// NaN (outside the reference's defined behaviour) sorts last.
+__device__ __forceinline__ uint32_t dist_key(float d)
+{
+    uint32_t b = __float_as_uint(d);
+    if ((b & 0x7fffffffu) > 0x7f800000u)
+        return 0xffffffffu;
+    if (b == 0x80000000u)
+        b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_dist(uint32_t k)
+{
+    if (k == 0xffffffffu)
+        return __uint_as_float(0x7fc00000u);
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v)
+{
+    uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64);
+    uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- per-wave sorted top-k of composite keys ----------------------------------
+// Composite keys are unique (they embed the row), so insertion order is irrelevant
+// and "strictly smaller than the current k-th" is the exact acceptance test: a row
+// that ties the k-th distance has a larger row index than every list entry of that
+// distance only if it was seen later -- and then it must lose (stable sort +
+// truncate, rank.rs:170-173).  The composite order encodes exactly that.
+
+// k <= 64: lane i holds the i-th smallest key; no memory traffic at all.
+struct WaveTopKReg {
+    static constexpr bool kInRegisters = true;
+    uint64_t e;
+    uint64_t tau;
+    uint32_t k;
+    __device__ __forceinline__ void init(uint32_t k_, uint64_t *)
+    {
+        k = k_;
+        e = kSentinel;
+        tau = kSentinel;
+    }
+    __device__ __forceinline__ void insert(uint64_t c)
+    {
+        const uint32_t lane = lane_id();
+        uint32_t p = (uint32_t)__popcll(__ballot(e < c));
+        uint64_t up = shfl_up1_u64(e);
+        e = lane < p ? e : (lane == p ? c : up);
+        tau = readlane64(e, k - 1);
+    }
+    __device__ __forceinline__ void offer(uint64_t comp)
+    {
+        uint64_t m = __ballot(comp < tau);
+        while (m) {
+            uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            uint64_t c = readlane64(comp, l);
+            if (c < tau)
+                insert(c);
+        }
+    }
+    // entry i (i < 64) for lane i
+    __device__ __forceinline__ uint64_t mine() const { return e; }
+    __device__ __forceinline__ void store(uint64_t *dst) const
+    {
+        if (lane_id() < k)
+            dst[lane_id()] = e;
+    }
+};
+
+// any k: the list lives in LDS (one per wave), ascending, kSentinel padded.
+struct WaveTopKLds {
+    static constexpr bool kInRegisters = false;
+    uint64_t *L;
+    uint64_t tau;
+    uint32_t k;
+    __device__ __forceinline__ void init(uint32_t k_, uint64_t *lds)
+    {
+        k = k_;
+        L = lds;
+        for (uint32_t i = lane_id(); i < k; i += 64)
+            L[i] = kSentinel;
+        tau = kSentinel;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void insert(uint64_t c)
+    {
+        const uint32_t lane = lane_id();
+        uint32_t p = 0;
+        for (uint32_t base = 0; base < k; base += 64) {
+            uint32_t idx = base + lane;
+            uint64_t v = idx < k ? L[idx] : kSentinel;
+            p += (uint32_t)__popcll(__ballot(v < c));
+        }
+        // shift [p, k-2] up by one, top chunk first; one wave = one instruction
+        // stream, LDS executes a wave's instructions in order, the barriers only
+        // stop the compiler from moving a chunk's store above the next chunk's load.
+        for (int base = (int)(((k - 1) / 64) * 64); base >= 0; base -= 64) {
+            if ((uint32_t)base + 63u < p)
+                break;
+            uint32_t idx = (uint32_t)base + lane;
+            uint64_t v = idx < k ? L[idx] : kSentinel;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (idx >= p && idx + 1 < k)
+                L[idx + 1] = v;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0)
+            L[p] = c;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        tau = L[k - 1];
+    }
+    __device__ __forceinline__ void offer(uint64_t comp)
+    {
+        uint64_t m = __ballot(comp < tau);
+        while (m) {
+            uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            uint64_t c = readlane64(comp, l);
+            if (c < tau)
+                insert(c);
+        }
+    }
+    __device__ __forceinline__ void store(uint64_t *dst) const
+    {
+        for (uint32_t i = lane_id(); i < k; i += 64)
+            dst[i] = L[i];
+    }
+};
+
+// ---- distance accumulation -----------------------------------------------------
+// `q` is wave-uniform (kernel argument + uniform offsets): the compiler emits
+// s_load and feeds SGPR operands.  Strictly sequential per lane.
+
+template <int METRIC>
+__device__ __forceinline__ float acc_step(float acc, float qv, float xv)
+{
+    if (METRIC == VFSX_EUCLIDEAN) { // rank.rs:284: (a - b).powi(2), a = query
+        float diff = f_sub(qv, xv);
+        return f_add(acc, f_mul(diff, diff));
+    } else { // rank.rs:293: a * b
+        return f_add(acc, f_mul(qv, xv));
+    }
+}
+
+template <int METRIC>
+__device__ __forceinline__ float acc_chunk_f32(float acc, const uint4 v, const float *__restrict__ q)
+{
+    acc = acc_step<METRIC>(acc, q[0], __uint_as_float(v.x));
+    acc = acc_step<METRIC>(acc, q[1], __uint_as_float(v.y));
+    acc = acc_step<METRIC>(acc, q[2], __uint_as_float(v.z));
+    acc = acc_step<METRIC>(acc, q[3], __uint_as_float(v.w));
+    return acc;
+}
+
+// i8: the byte indexes a per-bank replica of the 256-entry dequant table in LDS
+// (lut_s[u * 32 + (lane & 31)]): lane l always hits bank l & 31 -> conflict free.
+template <int METRIC>
+__device__ __forceinline__ float acc_word_i8(float acc, uint32_t w, const float *__restrict__ q,
+                                             const float *lut_lane)
+{
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        uint32_t u = (w >> (8 * b)) & 0xffu;
+        float xv = lut_lane[u * 32u]; // (q as f32) / scale, vector.rs:135-139
+        acc = acc_step<METRIC>(acc, q[b], xv);
+    }
+    return acc;
+}
+
+template <int METRIC>
+__device__ __forceinline__ float acc_chunk_i8(float acc, const uint4 v, const float *__restrict__ q,
+                                              const float *lut_lane)
+{
+    acc = acc_word_i8<METRIC>(acc, v.x, q + 0, lut_lane);
+    acc = acc_word_i8<METRIC>(acc, v.y, q + 4, lut_lane);
+    acc = acc_word_i8<METRIC>(acc, v.z, q + 8, lut_lane);
+    acc = acc_word_i8<METRIC>(acc, v.w, q + 12, lut_lane);
+    return acc;
+}
+
+// ---- the scan kernel -------------------------------------------------------------
+// grid = (n_lists, nq); block = 256 = 4 waves.  Wave w of the launch walks
+// row-blocks w, w + W, w + 2W, ... in ascending order.
+template <int DTYPE, int METRIC, typename TopK, int UNROLL>
+__global__ __launch_bounds__(kBlock) void scan_kernel(
+    const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
+    const float *__restrict__ queries, const float *__restrict__ q_norms,
+    const float *__restrict__ lut, uint64_t *__restrict__ lists, uint32_t n_rows, uint32_t d_chunks,
+    uint32_t n_rowblocks, uint32_t q_stride, uint32_t k, uint32_t n_lists)
+{
+    constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
+    extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)] lists
+    __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t qi = blockIdx.y;
+    const uint32_t list_stride = k > 64u ? k : 64u;
+
+    if (DTYPE == VFSX_I8) {
+        for (uint32_t i = threadIdx.x; i < 256u * 32u; i += kBlock)
+            lut_s[i] = lut[i >> 5];
+        __syncthreads();
+    }
+    const float *lut_lane = lut_s + (lane & 31u);
+
+    const float *__restrict__ q = queries + (size_t)qi * q_stride;
+    TopK top;
+    top.init(k, dyn_lds + wave * list_stride);
+
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wave;
+    float qn = 0.0f;
+    if (METRIC == VFSX_COSINE)
+        qn = q_norms[qi];
+
+    for (uint32_t blk = wave_global; blk < n_rowblocks; blk += n_waves) {
+        const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
+        float acc = 0.0f;
+        uint32_t c = 0;
+        for (; c + UNROLL <= d_chunks; c += UNROLL) {
+            uint4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                v[u] = p[(size_t)(c + u) * 64u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (DTYPE == VFSX_I8)
+                    acc = acc_chunk_i8<METRIC>(acc, v[u], q + (c + u) * EPC, lut_lane);
+                else
+                    acc = acc_chunk_f32<METRIC>(acc, v[u], q + (c + u) * EPC);
+            }
+        }
+        for (; c < d_chunks; ++c) {
+            uint4 v = p[(size_t)c * 64u];
+            if (DTYPE == VFSX_I8)
+                acc = acc_chunk_i8<METRIC>(acc, v, q + c * EPC, lut_lane);
+            else
+                acc = acc_chunk_f32<METRIC>(acc, v, q + c * EPC);
+        }
+        const uint32_t row = blk * 64u + lane;
+        uint64_t comp = kSentinel;
+        if (row < n_rows) {
+            float dist;
+            if (METRIC == VFSX_EUCLIDEAN) {
+                dist = f_sqrt(acc); // rank.rs:286
+            } else {                    // rank.rs:299: 1.0 - (dot / (norm_1 * norm_2))
+                float den = f_mul(qn, row_norms[row]);
+                dist = f_sub(1.0f, f_div(acc, den));
+            }
+            comp = ((uint64_t)dist_key(dist) << 32) | row;
+        }
+        top.offer(comp);
+    }
+
+    // fold the 4 waves' lists into wave 0's, then one list per workgroup to HBM
+    uint64_t *mine = dyn_lds + wave * list_stride;
+    __syncthreads(); // (TopKLds: lists already live there; Reg: publish them)
+    if (TopK::kInRegisters) {
+        mine[lane] = kSentinel;
+        top.store(mine);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const uint64_t *other = dyn_lds + w * list_stride;
+            for (uint32_t base = 0; base < k; base += 64) {
+                uint32_t idx = base + lane;
+                uint64_t comp = idx < k ? other[idx] : kSentinel;
+                top.offer(comp);
+            }
+        }
+        top.store(lists + ((size_t)qi * n_lists + blockIdx.x) * k);
+    }
+}
+
+// ---- select: merge the per-workgroup lists of one query, emit hits ----------------
+template <typename TopK>
+__global__ __launch_bounds__(kBlock) void select_kernel(const uint64_t *__restrict__ lists,
+                                                        const uint64_t *__restrict__ ids,
+                                                        vfsx_hit *__restrict__ out, uint64_t row_base,
+                                                        uint64_t id_base, uint32_t n_lists, uint32_t k)
+{
+    extern __shared__ __align__(16) uint64_t dyn_lds[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t list_stride = k > 64u ? k : 64u;
+    const uint64_t *__restrict__ src = lists + (size_t)qi * n_lists * k;
+    const uint64_t total = (uint64_t)n_lists * k;
+
+    TopK top;
+    top.init(k, dyn_lds + wave * list_stride);
+    // wave-uniform bases; four independent loads in flight per lane
+    uint64_t base = (uint64_t)wave * 64u;
+    for (; base + 3u * kBlock + 64u <= total; base += 4u * kBlock) {
+        uint64_t c0 = src[base + lane], c1 = src[base + kBlock + lane];
+        uint64_t c2 = src[base + 2u * kBlock + lane], c3 = src[base + 3u * kBlock + lane];
+        top.offer(c0);
+        top.offer(c1);
+        top.offer(c2);
+        top.offer(c3);
+    }
+    for (; base < total; base += kBlock) {
+        uint64_t idx = base + lane;
+        uint64_t c = idx < total ? src[idx] : kSentinel;
+        top.offer(c);
+    }
+
+    uint64_t *mine = dyn_lds + wave * list_stride;
+    __syncthreads();
+    if (TopK::kInRegisters) {
+        mine[lane] = kSentinel;
+        top.store(mine);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const uint64_t *other = dyn_lds + w * list_stride;
+            for (uint32_t base = 0; base < k; base += 64) {
+                uint32_t idx = base + lane;
+                uint64_t comp = idx < k ? other[idx] : kSentinel;
+                top.offer(comp);
+            }
+        }
+        top.store(mine);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        for (uint32_t j = lane; j < k; j += 64) {
+            uint64_t comp = mine[j];
+            vfsx_hit h;
+            if (comp == kSentinel) {
+                h.dist = __uint_as_float(0x7fc00000u);
+                h.flags = 0;
+                h.row = ~0ull;
+                h.id = ~0ull;
+            } else {
+                uint32_t r = (uint32_t)comp;
+                h.dist = key_dist((uint32_t)(comp >> 32));
+                h.flags = 1;
+                h.row = row_base + r;
+                h.id = ids ? ids[r] : id_base + r;
+            }
+            out[(size_t)qi * k + j] = h;
+        }
+    }
+}
+
+// ---- query preparation: zero-padded copy + ||q|| in the reference's order ----------
+__global__ void query_prep_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
+                                  float *__restrict__ q_pad, uint32_t q_stride,
+                                  float *__restrict__ q_norms)
+{
+    uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq)
+        return;
+    const float *src = q_in + (size_t)qi * dim;
+    float s = 0.0f;
+    for (uint32_t j = 0; j < dim; ++j) { // rank.rs:296: map(x.powi(2)).sum().sqrt()
+        float v = src[j];
+        s = f_add(s, f_mul(v, v));
+        if (q_pad)
+            q_pad[(size_t)qi * q_stride + j] = v;
+    }
+    if (q_pad)
+        for (uint32_t j = dim; j < q_stride; ++j)
+            q_pad[(size_t)qi * q_stride + j] = 0.0f;
+    if (q_norms)
+        q_norms[qi] = f_sqrt(s);
+}
+
+__global__ void lut_kernel(float scale, float *__restrict__ lut)
+{
+    uint32_t u = threadIdx.x;                      // raw byte
+    float f = (float)(int)(int8_t)(uint8_t)u;      // val as f32
+    lut[u] = f_div(f, scale);                  // vector.rs:138
+}
+
+// ---- ingest: row-major staging -> rb64 ------------------------------------------------
+__device__ __forceinline__ int quantize_one(float v, float scale)
+{ // vector.rs:106 with Some(scale): (val * scale).round() as i8  (saturating, NaN -> 0)
+    float p = f_mul(v, scale);
+    float r = roundf(p); // half away from zero, exact
+    if (r != r)
+        return 0;
+    if (r >= 127.0f)
+        return 127;
+    if (r <= -128.0f)
+        return -128;
+    return (int)r;
+}
+
+template <int MODE>
+__global__ void ingest_kernel(const void *__restrict__ staging, uint64_t n, uint32_t dim,
+                              uint4 *__restrict__ corpus, uint32_t d_chunks, uint64_t row0,
+                              float scale, uint64_t first_blk, uint64_t total)
+{
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total)
+        return;
+    uint32_t lane = (uint32_t)(t & 63u);
+    uint64_t cb = t >> 6;
+    uint32_t c = (uint32_t)(cb % d_chunks);
+    uint64_t b = first_blk + cb / d_chunks;
+    uint64_t row = b * 64u + lane;
+    if (row < row0 || row >= row0 + n)
+        return;
+    uint64_t i = row - row0;
+    uint4 out;
+    if (MODE == 0) {
+        const float *src = (const float *)staging + i * dim;
+        uint32_t j = c * 4u;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            f[e] = (j + e < dim) ? src[j + e] : 0.0f;
+        out = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                         __float_as_uint(f[3]));
+    } else {
+        uint32_t j = c * 16u;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            uint32_t byte = 0;
+            if (j + e < dim) {
+                if (MODE == 1)
+                    byte = ((const uint8_t *)staging)[i * dim + j + e];
+                else
+                    byte = (uint32_t)quantize_one(((const float *)staging)[i * dim + j + e], scale) & 0xffu;
+            }
+            w[e >> 2] |= byte << (8 * (e & 3));
+        }
+        out = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    corpus[(b * d_chunks + c) * 64u + lane] = out;
+}
+
+// ---- row norms (cosine): sqrt(sum x_j^2), sequential, rank.rs:297 ----------------------
+template <int DTYPE>
+__global__ void row_norms_kernel(const uint4 *__restrict__ corpus, uint32_t d_chunks,
+                                 const float *__restrict__ lut, uint64_t row0, uint64_t n,
+                                 float *__restrict__ row_norms, uint64_t first_blk)
+{
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t row = first_blk * 64u + t;
+    if (row < row0 || row >= row0 + n)
+        return;
+    uint64_t b = row >> 6;
+    uint32_t lane = (uint32_t)(row & 63u);
+    const uint4 *p = corpus + b * d_chunks * 64u + lane;
+    float s = 0.0f;
+    for (uint32_t c = 0; c < d_chunks; ++c) {
+        uint4 v = p[(size_t)c * 64u];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (DTYPE == VFSX_I8) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float x = lut[(w[e >> 2] >> (8 * (e & 3))) & 0xffu];
+                s = f_add(s, f_mul(x, x));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = __uint_as_float(w[e]);
+                s = f_add(s, f_mul(x, x));
+            }
+        }
+    }
+    row_norms[row] = f_sqrt(s);
+}
+
+// ---- synthetic fill (benchmark utility) ---------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float synth_value(uint64_t seed, uint64_t row, uint32_t dim, uint32_t col)
+{
+    uint64_t u = splitmix64(seed + row * (uint64_t)dim + col);
+    uint32_t m = (uint32_t)(u >> 40);
+    return f_sub(f_mul((float)m, 1.0f / 8388608.0f), 1.0f);
+}
+
+template <int DTYPE>
+__global__ void fill_synthetic_kernel(uint4 *__restrict__ corpus, uint32_t dim, uint32_t d_chunks,
+                                      uint64_t row0_local, uint64_t n, uint64_t seed,
+                                      uint64_t synth_row0, float scale, uint64_t first_blk,
+                                      uint64_t total)
+{
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total)
+        return;
+    uint32_t lane = (uint32_t)(t & 63u);
+    uint64_t cb = t >> 6;
+    uint32_t c = (uint32_t)(cb % d_chunks);
+    uint64_t b = first_blk + cb / d_chunks;
+    uint64_t row = b * 64u + lane;
+    if (row < row0_local || row >= row0_local + n)
+        return;
+    uint64_t srow = synth_row0 + (row - row0_local);
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (DTYPE == VFSX_I8) {
+        uint32_t j = c * 16u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (j + e < dim)
+                w[e >> 2] |= ((uint32_t)quantize_one(synth_value(seed, srow, dim, j + e), scale) & 0xffu)
+                             << (8 * (e & 3));
+    } else {
+        uint32_t j = c * 4u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j + e < dim)
+                w[e] = __float_as_uint(synth_value(seed, srow, dim, j + e));
+    }
+    corpus[(b * d_chunks + c) * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- gather rows back (hydration) -----------------------------------------------------------
+template <int DTYPE, int AS_F32>
+__global__ void get_rows_kernel(const uint4 *__restrict__ corpus, uint32_t dim, uint32_t d_chunks,
+                                const float *__restrict__ lut, const uint64_t *__restrict__ rows,
+                                uint64_t n, void *__restrict__ out)
+{
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * dim)
+        return;
+    uint64_t i = t / dim;
+    uint32_t j = (uint32_t)(t % dim);
+    uint64_t row = rows[i];
+    const uint8_t *base = (const uint8_t *)(corpus + (row >> 6) * d_chunks * 64u + (row & 63u));
+    if (DTYPE == VFSX_I8) {
+        uint8_t u = base[(size_t)(j >> 4) * 1024u + (j & 15u)];
+        if (AS_F32)
+            ((float *)out)[t] = lut[u];
+        else
+            ((uint8_t *)out)[t] = u;
+    } else {
+        float f = *(const float *)(base + (size_t)(j >> 2) * 1024u + (j & 3u) * 4u);
+        ((float *)out)[t] = f;
+    }
+}
+
+// ---- cross-shard merge of ranked hit lists ------------------------------------------------------
+// in: [n_lists][nq][k]; one workgroup per query; rank-by-counting under the strict
+// total order (key(dist), row, input index).
+__global__ __launch_bounds__(kBlock) void merge_hits_kernel(const vfsx_hit *__restrict__ in,
+                                                            uint32_t n_lists, uint32_t nq, uint32_t k,
+                                                            vfsx_hit *__restrict__ out)
+{
+    const uint32_t qi = blockIdx.x;
+    const uint32_t total = n_lists * k;
+    for (uint32_t a = threadIdx.x; a < total; a += kBlock) {
+        const vfsx_hit ha = in[((size_t)(a / k) * nq + qi) * k + (a % k)];
+        const uint32_t va = ha.flags & 1u;
+        const uint32_t ka = dist_key(ha.dist);
+        uint32_t rank = 0;
+        for (uint32_t b = 0; b < total; ++b) {
+            const vfsx_hit hb = in[((size_t)(b / k) * nq + qi) * k + (b % k)];
+            const uint32_t vb = hb.flags & 1u;
+            const uint32_t kb = dist_key(hb.dist);
+            bool less;
+            if (va != vb)
+                less = vb > va; // valid before invalid
+            else if (kb != ka)
+                less = kb < ka;
+            else if (hb.row != ha.row)
+                less = hb.row < ha.row;
+            else
+                less = b < a;
+            rank += less ? 1u : 0u;
+        }
+        if (rank < k)
+            out[(size_t)qi * k + rank] = ha;
+    }
+}
+
+} // namespace
+
+// ---- launchers --------------------------------------------------------------------------------------
+
+template <int DTYPE, int METRIC>
+static hipError_t launch_scan_t(const ScanArgs &a, uint32_t nq, uint32_t grid_x, hipStream_t s)
+{
+    dim3 grid(grid_x, nq), block(kBlock);
+    const uint32_t list_stride = a.k > 64u ? a.k : 64u;
+    const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
+    constexpr int U = 8;
+    if (a.k <= kMaxRegisterK) {
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, U>), grid, block, lds, s, a.corpus,
+                           a.row_norms, a.queries, a.q_norms, a.lut, a.lists, a.n_rows, a.d_chunks,
+                           a.n_rowblocks, a.q_stride, a.k, a.n_lists);
+    } else {
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, U>), grid, block, lds, s, a.corpus,
+                           a.row_norms, a.queries, a.q_norms, a.lut, a.lists, a.n_rows, a.d_chunks,
+                           a.n_rowblocks, a.q_stride, a.k, a.n_lists);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x,
+                       hipStream_t s)
+{
+    const bool cosine = (metric == VFSX_COSINE || metric == VFSX_SIMD_COSINE);
+    if (dtype == VFSX_I8)
+        return cosine ? launch_scan_t<VFSX_I8, VFSX_COSINE>(a, nq, grid_x, s)
+                      : launch_scan_t<VFSX_I8, VFSX_EUCLIDEAN>(a, nq, grid_x, s);
+    return cosine ? launch_scan_t<VFSX_F32, VFSX_COSINE>(a, nq, grid_x, s)
+                  : launch_scan_t<VFSX_F32, VFSX_EUCLIDEAN>(a, nq, grid_x, s);
+}
+
+hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)
+{
+    const uint32_t list_stride = a.k > 64u ? a.k : 64u;
+    const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
+    if (a.k <= kMaxRegisterK)
+        hipLaunchKernelGGL((select_kernel<WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.lists, a.ids,
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k);
+    else
+        hipLaunchKernelGGL((select_kernel<WaveTopKLds>), dim3(nq), dim3(kBlock), lds, s, a.lists, a.ids,
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k);
+    return hipGetLastError();
+}
+
+hipError_t launch_query_prep(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
+                             uint32_t q_stride, float *d_q_norms, hipStream_t s)
+{
+    hipLaunchKernelGGL(query_prep_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_queries_in, nq, dim,
+                       d_q_padded, q_stride, d_q_norms);
+    return hipGetLastError();
+}
+
+hipError_t launch_lut(float scale, float *d_lut, hipStream_t s)
+{
+    hipLaunchKernelGGL(lut_kernel, dim3(1), dim3(256), 0, s, scale, d_lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest(int mode, const void *d_staging, uint64_t n, uint32_t dim, uint4 *corpus,
+                         uint32_t d_chunks, uint64_t row0, float scale, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint64_t first_blk = row0 / 64u, last_blk = (row0 + n - 1) / 64u;
+    const uint64_t total = (last_blk - first_blk + 1) * d_chunks * 64u;
+    const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL((ingest_kernel<0>), grid, block, 0, s, d_staging, n, dim, corpus, d_chunks,
+                           row0, scale, first_blk, total);
+    else if (mode == 1)
+        hipLaunchKernelGGL((ingest_kernel<1>), grid, block, 0, s, d_staging, n, dim, corpus, d_chunks,
+                           row0, scale, first_blk, total);
+    else
+        hipLaunchKernelGGL((ingest_kernel<2>), grid, block, 0, s, d_staging, n, dim, corpus, d_chunks,
+                           row0, scale, first_blk, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_norms(int dtype, const uint4 *corpus, uint32_t d_chunks, const float *d_lut,
+                            uint64_t row0, uint64_t n, float *row_norms, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint64_t first_blk = row0 / 64u, last_blk = (row0 + n - 1) / 64u;
+    const uint64_t total = (last_blk - first_blk + 1) * 64u;
+    const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+    if (dtype == VFSX_I8)
+        hipLaunchKernelGGL((row_norms_kernel<VFSX_I8>), grid, block, 0, s, corpus, d_chunks, d_lut, row0,
+                           n, row_norms, first_blk);
+    else
+        hipLaunchKernelGGL((row_norms_kernel<VFSX_F32>), grid, block, 0, s, corpus, d_chunks, d_lut, row0,
+                           n, row_norms, first_blk);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_synthetic(int dtype, uint4 *corpus, uint32_t dim, uint32_t d_chunks,
+                                 uint64_t row0_local, uint64_t n, uint64_t seed, uint64_t synth_row0,
+                                 float scale, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint64_t first_blk = row0_local / 64u, last_blk = (row0_local + n - 1) / 64u;
+    const uint64_t total = (last_blk - first_blk + 1) * d_chunks * 64u;
+    const uint64_t nblocks = (total + 255) / 256;
+    if (nblocks > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    const dim3 grid((uint32_t)nblocks), block(256);
+    if (dtype == VFSX_I8)
+        hipLaunchKernelGGL((fill_synthetic_kernel<VFSX_I8>), grid, block, 0, s, corpus, dim, d_chunks,
+                           row0_local, n, seed, synth_row0, scale, first_blk, total);
+    else
+        hipLaunchKernelGGL((fill_synthetic_kernel<VFSX_F32>), grid, block, 0, s, corpus, dim, d_chunks,
+                           row0_local, n, seed, synth_row0, scale, first_blk, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_get_rows(int dtype, const uint4 *corpus, uint32_t dim, uint32_t d_chunks,
+                           const float *d_lut, const uint64_t *d_rows, uint64_t n, int as_f32,
+                           void *d_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint64_t total = n * dim;
+    const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+    if (dtype == VFSX_I8) {
+        if (as_f32)
+            hipLaunchKernelGGL((get_rows_kernel<VFSX_I8, 1>), grid, block, 0, s, corpus, dim, d_chunks,
+                               d_lut, d_rows, n, d_out);
+        else
+            hipLaunchKernelGGL((get_rows_kernel<VFSX_I8, 0>), grid, block, 0, s, corpus, dim, d_chunks,
+                               d_lut, d_rows, n, d_out);
+    } else {
+        hipLaunchKernelGGL((get_rows_kernel<VFSX_F32, 1>), grid, block, 0, s, corpus, dim, d_chunks, d_lut,
+                           d_rows, n, d_out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
+                             vfsx_hit *d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(merge_hits_kernel, dim3(nq), dim3(kBlock), 0, s, d_in, n_lists, nq, k, d_out);
+    return hipGetLastError();
+}
+
+} // namespace vfsx
