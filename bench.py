@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- exact top-10 QPS of the vfsx single-query scan on MI355X.
+
+Contract (see the task's bench rules): `python bench.py --gpus N --steps K --warmup W`.
+  * N = 1: workload C2 = BASELINE.json configs[1]: 1M x 768 f32 Cosine, exact top-10,
+    single-query scans.  A step = `--queries-per-step` distinct queries, each scanned
+    by its own kernel launch (the corpus is re-read from HBM for every query).
+  * N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every
+    rank holds its own 1M x 768 shard of a row-sharded N*1M-row corpus; every query is
+    scanned on every shard, the per-shard top-10 lists of a step are exchanged with ONE
+    RCCL all-gather and merged on the device by (distance, global row).
+    `value` = shard scans per second = N x (queries/s answered against the whole
+    corpus): the units all ranks processed / max-over-ranks time.  `qps_global` is the
+    plain queries/s against the N*1M-row corpus.
+Inputs are resident in HBM before the timed region (synthetic, generated on device).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (rows per GPU, dim, quantize, metric, label)
+    "c2": (1_000_000, 768, False, 1, "C2 1Mx768 f32 Cosine exact top-10, single-query scan"),
+    "c2e": (1_000_000, 768, False, 0, "1Mx768 f32 Euclidean exact top-10, single-query scan"),
+    "c3": (10_000_000, 128, True, 0, "C3 10Mx128 int8 QuantizedVector Euclidean exact top-10"),
+    "c1": (100_000, 128, False, 2, "C1 100kx128 f32 SimdEuclidean exact top-10"),
+    "c5": (12_500_000, 768, False, 0, "C5 shard 12.5Mx768 f32 Euclidean (100Mx768 over 8 GPUs)"),
+}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--queries-per-step", type=int, default=16)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=262144)
+    ap.add_argument("--cpu-sample-queries", type=int, default=48)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import vfs_amd
+    from vfs_amd import sharded, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
+                  f"(one rank per GPU)", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (vfs_amd has no CPU path)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows, dim, quantize, metric, label = WORKLOADS[args.workload]
+    if args.rows:
+        rows = args.rows
+    k = args.k
+    qps_step = args.queries_per_step
+    elem = 1 if quantize else 4
+
+    corpus = vfs_amd.Corpus(dim, quantize=quantize, capacity_rows=rows, device=local_rank)
+    corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
+    corpus.set_row_base(rank * rows)
+
+    n_q = (args.steps + args.warmup) * qps_step
+    q_host = synth.rows_f32(synth.QUERY_SEED, 0, n_q, dim)
+    d_q = torch.from_numpy(q_host).to(dev)
+    hit_words = 6  # vfsx_hit = 24 bytes = 6 x u32
+    d_local = torch.zeros((qps_step, k, hit_words), dtype=torch.int32, device=dev)
+
+    def run_step(step_idx: int) -> None:
+        stream = torch.cuda.current_stream().cuda_stream
+        base = step_idx * qps_step
+        for j in range(qps_step):  # one scan launch per query: "single-query scan"
+            corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
+        if world > 1:  # ONE all-gather per step (queries_per_step x k x 24 B per rank), device merge
+            sharded.exchange_and_merge(d_local, k, device_index=local_rank)
+
+    def fence() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        run_step(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        run_step(args.warmup + s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline leg: same launches, scan kernel bracketed by HIP events on its own stream
+    corpus.set_profiling(True)
+    for s in range(min(args.steps, 8)):
+        base = (args.warmup + s) * qps_step
+        stream = torch.cuda.current_stream().cuda_stream
+        for j in range(qps_step):
+            corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
+    torch.cuda.synchronize()
+    scan_ms, scan_launches = corpus.scan_time_ms()
+    corpus.set_profiling(False)
+    avg_ms = scan_ms / max(scan_launches, 1)
+    algo_bytes = rows * dim * elem  # N*d*sizeof(elem) per query, ids/norms excluded
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+
+    queries = args.steps * qps_step
+    qps_global = queries / elapsed
+    value = qps_global * world  # shard scans per second (see module docstring)
+    out = {
+        "metric": "exact top-10 QPS (single-query scan; shard scans/s when row-sharded)",
+        "value": round(value, 3),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if not quantize else "f32 arithmetic on i8 storage",
+        "data": "synthetic",
+        "config": {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k,
+                   "queries_per_step": qps_step, "metric_fn": ["euclidean", "cosine", "simd_euclidean",
+                                                                "simd_cosine"][metric],
+                   "sharding": f"row-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
+        "qps_global": round(qps_global, 3),
+        "hbm_gbps_aggregate": round(qps_global * algo_bytes * world / 1e9, 1),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "scan_kernel", "avg_kernel_ms": round(avg_ms, 5),
+                     "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, rows, dim, quantize, metric, k)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    corpus.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(args, rows, dim, quantize, metric, k):
+    """The oracle (oracle/vfs_oracle.c: the reference's scalar arithmetic, sequential
+    f32 sums, one core) timed on a bounded sample of the same workload."""
+    from oracle import c_oracle
+    from vfs_amd import synth
+    n = min(args.cpu_sample_rows, rows)
+    x = synth.rows_f32(synth.CORPUS_SEED, 0, n, dim)
+    if quantize:
+        x = c_oracle.quantize(x, 127.0)
+    qs = synth.rows_f32(synth.QUERY_SEED, 0, args.cpu_sample_queries, dim)
+    c_oracle.topk_scan(x[:1024], qs[0], metric, k)  # warm
+    t0 = time.perf_counter()
+    for q in qs:
+        c_oracle.topk_scan(x, q, metric, k)
+    dt = time.perf_counter() - t0
+    rows_per_s = n * len(qs) / dt
+    return {"value": round(rows_per_s / rows, 4), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"{len(qs)} queries x first {n} rows of the same synthetic corpus "
+                      f"({dt:.1f} s of CPU), rows/s scaled to the full {rows}-row corpus",
+            "rows_per_s": round(rows_per_s, 1)}
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,144 @@
+"""GPU: golden fixtures, the Ranker mirror, device-resident search and the hit merge,
+all through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import golden_util
+
+pytestmark = pytest.mark.gpu
+
+CASES, QUANT = golden_util.load()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_golden_on_gpu(case):
+    import vfs_amd
+    rows = case["rows"]
+    c = vfs_amd.Corpus(rows.shape[1], quantize=case["quantized"])
+    c.append(rows, ids=case["ids"])
+    r = vfs_amd.Ranker(vfs_amd.SearchType.Exact, vfs_amd.DistanceMethod(case["metric"]))
+    got = r.search(case["query"], case["batch"], case["limit"], c)
+    assert [g[0] for g in got] == case["expect_ids"].tolist()
+    assert (bits([g[1] for g in got]) == bits(case["expect_dist"])).all()
+    c.close()
+
+
+def test_device_lut_is_ieee_division():
+    import vfs_amd
+    for scale in (127.0, 100.0, 3.0, 0.37):
+        c = vfs_amd.Corpus(256, quantize=True, scale=scale)
+        allq = np.arange(-128, 128).astype(np.int8)[None, :]
+        c.append(allq)
+        want = (allq.astype(np.float32) / np.float32(scale)).astype(np.float32)
+        assert (bits(c.get_rows_f32([0])) == bits(want)).all()
+        c.close()
+
+
+def test_search_device_and_merge(oracle):
+    import torch
+    import vfs_amd
+    from vfs_amd import sharded
+    rng = np.random.default_rng(21)
+    n, d, k, nq = 9001, 48, 10, 5
+    rows = oracle.quantize(rng.uniform(-10, 10, (n, d)).round(4).astype(np.float32), 127.0)
+    queries = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    cuts = sharded.split_rows(n, 3)
+    shards = []
+    for lo, hi in cuts:
+        c = vfs_amd.Corpus(d, quantize=True)
+        c.append(rows[lo:hi], ids=np.arange(lo + 1, hi + 1, dtype=np.uint64))
+        c.set_row_base(lo)
+        shards.append(c)
+    dq = torch.from_numpy(queries).cuda()
+    for metric in (0, 1):
+        lists = torch.zeros((3, nq, k, 6), dtype=torch.int32, device="cuda")
+        for g, c in enumerate(shards):
+            c.search_device(dq.data_ptr(), nq, k, metric, lists[g].data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+        out = torch.zeros((nq, k, 6), dtype=torch.int32, device="cuda")
+        lib = vfs_amd.load()
+        vfs_amd._lib.check(lib.vfsx_merge_hits_device(C.c_void_p(lists.data_ptr()), 3, nq, k,
+                                                      C.c_void_p(out.data_ptr()), 0,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        ids, dist, cnt = sharded.hits_to_arrays(out)
+        # host merge of the same lists agrees with the device merge
+        g = lists.cpu().numpy().view(np.uint8).reshape(3, nq, k, 24).view(sharded.HIT_DTYPE).reshape(3, nq, k)
+        hm = sharded.merge_hits_host(g, k)
+        assert (hm["id"] == ids).all() and (bits(hm["dist"]) == bits(dist)).all()
+        for qi in range(nq):
+            oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k)
+            assert (ids[qi] == oi).all() and (bits(dist[qi]) == bits(od)).all()
+    for c in shards:
+        c.close()
+
+
+def test_multi_query_host_api(oracle):
+    import vfs_amd
+    rng = np.random.default_rng(33)
+    n, d, k, nq = 4000, 20, 7, 9
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    for metric in (0, 1, 2, 3):
+        ids, dist, cnt = c.search_batch(queries, k, metric)
+        for qi in range(nq):
+            oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k)
+            assert cnt[qi] == k and (ids[qi] == oi).all() and (bits(dist[qi]) == bits(od)).all()
+    c.close()
+
+
+def test_growth_beyond_capacity(oracle):
+    import vfs_amd
+    rng = np.random.default_rng(34)
+    d = 12
+    rows = rng.uniform(-1, 1, (1000, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, capacity_rows=64)
+    for a in range(0, 1000, 137):
+        c.append(rows[a:a + 137])
+    q = rng.uniform(-1, 1, d).astype(np.float32)
+    ids, dist, cnt = c.search_batch(q, 10, 1)
+    oi, od, _ = oracle.topk_scan(rows, q, 1, 10)
+    assert (ids[0] == oi).all() and (bits(dist[0]) == bits(od)).all()
+    c.close()
+
+
+def test_error_behaviour():
+    import vfs_amd
+    c = vfs_amd.Corpus(8)
+    with pytest.raises(vfs_amd.VfsxError) as e:
+        c.append(np.zeros((3, 7), np.float32))  # tcp.rs:307-312 -> 400
+    assert e.value.kind == "invalid_vector" and "Expected 8, got 7" in str(e.value)
+    with pytest.raises(vfs_amd.VfsxError) as e:
+        c.search_batch(np.zeros(9, np.float32), 5, 0)  # tcp.rs:371-376 -> 400
+    assert "Query vector dimension mismatch" in str(e.value)
+    with pytest.raises(vfs_amd.VfsxError):
+        c.search_batch(np.zeros(8, np.float32), 0, 0)
+    with pytest.raises(vfs_amd.VfsxError):
+        c.search_batch(np.zeros(8, np.float32), 5000, 0)
+    with pytest.raises(vfs_amd.VfsxError):
+        c.search_batch(np.zeros(8, np.float32), 5, 9)
+    # empty corpus: zero hits, no error
+    ids, dist, cnt = c.search_batch(np.zeros(8, np.float32), 5, 0)
+    assert cnt[0] == 0
+    c.close()
+
+
+def test_nan_sorts_last_documented_deviation():
+    """Zero-norm rows give NaN under cosine (rank.rs:299); the reference's order is then
+    unspecified.  vfsx: NaN sorts after every number, and is only returned when k > #non-NaN."""
+    import vfs_amd
+    rows = np.array([[1, 0], [0, 0], [0, 1], [0, 0], [1, 1]], np.float32)
+    c = vfs_amd.Corpus(2)
+    c.append(rows)
+    ids, dist, cnt = c.search_batch(np.array([1, 0], np.float32), 5, 1)
+    assert cnt[0] == 5 and ids[0].tolist() == [1, 5, 3, 2, 4]
+    assert np.isnan(dist[0, 3:]).all() and not np.isnan(dist[0, :3]).any()
+    c.close()

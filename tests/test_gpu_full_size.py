@@ -1,0 +1,92 @@
+"""GPU: parity at BASELINE.json's full single-GPU sizes (C1, C2, C3), against the
+oracle on the same synthetic corpus, plus size-independent properties (shard-merge
+equals whole-corpus search; Simd* == scalar; k-prefix property)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED_C, SEED_Q = 0x5EED0001, 0x5EED0002
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_c1_100k_x128_simd_euclidean(oracle):
+    import vfs_amd
+    n, d = 100_000, 128
+    c = vfs_amd.Corpus(d)
+    c.fill_synthetic(SEED_C, n)
+    rows = oracle.synth_f32(SEED_C, 0, n, d)
+    qs = oracle.synth_f32(SEED_Q, 0, 4, d)
+    for q in qs:
+        for metric in (2, 0, 3):
+            ids, dist, cnt = c.search_batch(q, 10, metric)
+            oi, od, _ = oracle.topk_scan(rows, q, metric, 10)
+            assert (ids[0] == oi).all() and (bits(dist[0]) == bits(od)).all()
+    c.close()
+
+
+def test_c2_1m_x768_cosine(oracle):
+    import vfs_amd
+    n, d = 1_000_000, 768
+    c = vfs_amd.Corpus(d, capacity_rows=n)
+    c.fill_synthetic(SEED_C, n)
+    rows = oracle.synth_f32(SEED_C, 0, n, d)
+    q = oracle.synth_f32(SEED_Q, 0, 1, d)[0]
+    ids, dist, cnt = c.search_batch(q, 10, 1)
+    oi, od, _ = oracle.topk_scan(rows, q, 1, 10)
+    assert (ids[0] == oi).all() and (bits(dist[0]) == bits(od)).all()
+    # property: top-100 begins with top-10; Simd == scalar
+    ids100, dist100, _ = c.search_batch(q, 100, 3)
+    assert (ids100[0, :10] == ids[0]).all() and (bits(dist100[0, :10]) == bits(dist[0])).all()
+    assert (np.diff(dist100[0]) >= 0).all()
+    c.close()
+
+
+def test_c3_10m_x128_int8_euclidean(oracle):
+    import torch
+    import vfs_amd
+    from vfs_amd import sharded
+    n, d = 10_000_000, 128
+    c = vfs_amd.Corpus(d, quantize=True, capacity_rows=n)
+    c.fill_synthetic(SEED_C, n)
+    q = oracle.synth_f32(SEED_Q, 7, 1, d)[0]
+    ids, dist, cnt = c.search_batch(q, 10, 0)
+    # oracle over the full corpus, generated in slabs to bound host memory
+    best = None
+    slab = 1_000_000
+    parts = []
+    for r0 in range(0, n, slab):
+        rows = oracle.synth_i8(SEED_C, r0, slab, d)
+        oi, od, op = oracle.topk_scan(rows, q, 0, 10)
+        parts.append((od, op + r0))
+    od = np.concatenate([p[0] for p in parts])
+    op = np.concatenate([p[1] for p in parts])
+    order = np.lexsort((op, od))[:10]  # (distance, scan position)
+    assert (ids[0] == op[order] + 1).all()
+    assert (bits(dist[0]) == bits(od[order])).all()  # int8 distances bit-exact
+    # property: two half-corpora merged on the device == whole corpus
+    halves = []
+    for g, (lo, hi) in enumerate(sharded.split_rows(n, 2)):
+        h = vfs_amd.Corpus(d, quantize=True, capacity_rows=hi - lo)
+        h.fill_synthetic(SEED_C, hi - lo, row0=lo, id0=lo + 1)
+        h.set_row_base(lo)
+        halves.append(h)
+    dq = torch.from_numpy(q[None, :]).cuda()
+    lists = torch.zeros((2, 1, 10, 6), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for g, h in enumerate(halves):
+        h.search_device(dq.data_ptr(), 1, 10, 0, lists[g].data_ptr(), st)
+    out = torch.zeros((1, 10, 6), dtype=torch.int32, device="cuda")
+    vfs_amd._lib.check(vfs_amd.load().vfsx_merge_hits_device(C.c_void_p(lists.data_ptr()), 2, 1, 10,
+                                                             C.c_void_p(out.data_ptr()), 0, C.c_void_p(st)))
+    torch.cuda.synchronize()
+    mi, md, _ = sharded.hits_to_arrays(out)
+    assert (mi[0] == ids[0]).all() and (bits(md[0]) == bits(dist[0])).all()
+    for h in halves:
+        h.close()
+    c.close()

@@ -132,11 +132,13 @@ struct vfsx_corpus {
 
     // search workspace
     DeviceBuf<uint64_t> lists;
-    DeviceBuf<float> q_in, q_pad, q_norms;
+    DeviceBuf<float> q_in, q_pad;
     DeviceBuf<vfsx_hit> hits;
     DeviceBuf<uint64_t> row_idx;
     DeviceBuf<uint8_t> row_out;
     uint32_t max_blocks = 0;
+    int unroll_override = 0; // 0 = auto
+    int nt_override = 2;     // 2 = auto
 
     // profiling
     bool profiling = false;
@@ -324,23 +326,24 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 
     const uint32_t q_stride_pad = c->d_chunks * c->epc;
     const bool need_pad = (q_stride_pad != c->dim);
-    const bool cosine = is_cosine(metric);
     const float *q_ptr = d_queries;
     uint32_t q_stride = c->dim;
-    if (need_pad || cosine) {
-        if (need_pad)
-            c->q_pad.reserve((size_t)nq * q_stride_pad);
-        if (cosine)
-            c->q_norms.reserve(nq);
-        HIP_CHECK(vfsx::launch_query_prep(d_queries, nq, c->dim, need_pad ? c->q_pad.p : nullptr, q_stride_pad,
-                                          cosine ? c->q_norms.p : nullptr, s));
-        if (need_pad) {
-            q_ptr = c->q_pad.p;
-            q_stride = q_stride_pad;
-        }
+    if (need_pad) {
+        c->q_pad.reserve((size_t)nq * q_stride_pad);
+        HIP_CHECK(vfsx::launch_query_pad(d_queries, nq, c->dim, c->q_pad.p, q_stride_pad, s));
+        q_ptr = c->q_pad.p;
+        q_stride = q_stride_pad;
     }
 
     const uint32_t n_rowblocks = (uint32_t)((c->n_rows + 63u) / 64u);
+    // a corpus that fits the 256 MiB Infinity Cache is re-read from it: keep the default
+    // cache policy there, stream everything larger with nontemporal loads
+    const bool big = c->corpus_bytes(round_up64(c->n_rows)) > (192ull << 20);
+    const int nt = c->nt_override == 2 ? (big ? 1 : 0) : (c->nt_override ? 1 : 0);
+    int unroll = c->unroll_override;
+    if (unroll != 4 && unroll != 8 && unroll != 16)
+        unroll = c->dtype == VFSX_I8 ? 4 : (c->d_chunks >= 64 ? 16 : 8);
+    const int scan_variant = unroll * 2 + nt;
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + 3u) / 4u, c->max_blocks);
     // queries per launch: bounded by gridDim.y and by a 256 MiB list workspace
     uint32_t q_per_launch = nq;
@@ -357,7 +360,6 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
             a.corpus = c->d_corpus;
             a.row_norms = c->d_norms;
             a.queries = q_ptr + (size_t)q0 * q_stride;
-            a.q_norms = cosine ? c->q_norms.p + q0 : nullptr;
             a.lut = c->d_lut;
             a.lists = c->lists.p;
             a.n_rows = (uint32_t)c->n_rows;
@@ -368,7 +370,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
             a.n_lists = grid_x;
             size_t slot = 0;
             prof_begin(c, s, slot);
-            HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, s));
+            HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, s));
             prof_end(c, s, slot);
         }
         SelectArgs sa{};
@@ -447,7 +449,12 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->scale = dtype == VFSX_I8 ? scale : 1.0f;
         c->epc = vfsx::elems_per_chunk(dtype);
         c->d_chunks = (dim + c->epc - 1) / c->epc;
-        c->max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)env_u64("VFSX_BLOCKS_PER_CU", 8);
+        c->max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)env_u64("VFSX_BLOCKS_PER_CU", 4);
+        // scan variant (tuned on MI355X): deep unroll for long f32 rows,
+        // 4 for int8 (the dequant keeps the VALU/LDS busier); chosen per launch in
+        // search_device_impl together with the nontemporal hint.
+        c->unroll_override = (int)env_u64("VFSX_SCAN_UNROLL", 0);
+        c->nt_override = (int)env_u64("VFSX_SCAN_NT", 2);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)
@@ -487,7 +494,6 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->lists.release();
     c->q_in.release();
     c->q_pad.release();
-    c->q_norms.release();
     c->hits.release();
     c->row_idx.release();
     c->row_out.release();

@@ -26,7 +26,6 @@ struct ScanArgs {
     const uint4 *corpus;    // rb64 layout
     const float *row_norms; // [n_rows] sqrt(sum x^2), sequential order (cosine only)
     const float *queries;   // [nq][q_stride] f32, zero padded to d_chunks*epc
-    const float *q_norms;   // [nq] (cosine only)
     const float *lut;       // [256] f32 dequant table indexed by the raw byte (i8 only)
     uint64_t *lists;        // out: [nq][n_lists][k] composite keys, ascending, kSentinel padded
     uint32_t n_rows;
@@ -48,11 +47,11 @@ struct SelectArgs {
 };
 
 // launchers (vfsx_kernels.hip). All enqueue on `s` and return the launch status.
-hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x,
+hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant,
                        hipStream_t s);
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s);
-hipError_t launch_query_prep(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
-                             uint32_t q_stride, float *d_q_norms, hipStream_t s);
+hipError_t launch_query_pad(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
+                            uint32_t q_stride, hipStream_t s);
 hipError_t launch_lut(float scale, float *d_lut, hipStream_t s);
 // staging (row-major, n rows of `dim` src elements) -> rb64 rows [row0, row0+n)
 //   mode 0: f32 -> f32   1: i8 -> i8   2: f32 -> i8 (quantize, vector.rs:94-108)

@@ -189,65 +189,113 @@ struct WaveTopKLds {
 // ---- distance accumulation -----------------------------------------------------
 // `q` is wave-uniform (kernel argument + uniform offsets): the compiler emits
 // s_load and feeds SGPR operands.  Strictly sequential per lane.
+// Cosine also needs ||q|| (rank.rs:296, recomputed per candidate by the reference):
+// with WITH_QQ every lane folds q_j*q_j into a second accumulator in the same j
+// order while it walks its first row-block -- the VALU has >10x headroom under the
+// HBM stream, so this costs no time and saves a kernel launch per query.
+struct Acc {
+    float a;  // sum (q-x)^2  or  sum q*x
+    float qq; // sum q*q (cosine, first row-block of the wave only)
+};
 
-template <int METRIC>
-__device__ __forceinline__ float acc_step(float acc, float qv, float xv)
+template <int METRIC, bool WITH_QQ>
+__device__ __forceinline__ void acc_step(Acc &acc, float qv, float xv)
 {
     if (METRIC == VFSX_EUCLIDEAN) { // rank.rs:284: (a - b).powi(2), a = query
         float diff = f_sub(qv, xv);
-        return f_add(acc, f_mul(diff, diff));
+        acc.a = f_add(acc.a, f_mul(diff, diff));
     } else { // rank.rs:293: a * b
-        return f_add(acc, f_mul(qv, xv));
+        acc.a = f_add(acc.a, f_mul(qv, xv));
+        if (WITH_QQ)
+            acc.qq = f_add(acc.qq, f_mul(qv, qv));
     }
 }
 
-template <int METRIC>
-__device__ __forceinline__ float acc_chunk_f32(float acc, const uint4 v, const float *__restrict__ q)
+template <int METRIC, bool WITH_QQ>
+__device__ __forceinline__ void acc_chunk_f32(Acc &acc, const uint4 v, const float *__restrict__ q)
 {
-    acc = acc_step<METRIC>(acc, q[0], __uint_as_float(v.x));
-    acc = acc_step<METRIC>(acc, q[1], __uint_as_float(v.y));
-    acc = acc_step<METRIC>(acc, q[2], __uint_as_float(v.z));
-    acc = acc_step<METRIC>(acc, q[3], __uint_as_float(v.w));
-    return acc;
+    acc_step<METRIC, WITH_QQ>(acc, q[0], __uint_as_float(v.x));
+    acc_step<METRIC, WITH_QQ>(acc, q[1], __uint_as_float(v.y));
+    acc_step<METRIC, WITH_QQ>(acc, q[2], __uint_as_float(v.z));
+    acc_step<METRIC, WITH_QQ>(acc, q[3], __uint_as_float(v.w));
 }
 
 // i8: the byte indexes a per-bank replica of the 256-entry dequant table in LDS
 // (lut_s[u * 32 + (lane & 31)]): lane l always hits bank l & 31 -> conflict free.
-template <int METRIC>
-__device__ __forceinline__ float acc_word_i8(float acc, uint32_t w, const float *__restrict__ q,
-                                             const float *lut_lane)
+template <int METRIC, bool WITH_QQ>
+__device__ __forceinline__ void acc_word_i8(Acc &acc, uint32_t w, const float *__restrict__ q,
+                                            const float *lut_lane)
 {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         uint32_t u = (w >> (8 * b)) & 0xffu;
         float xv = lut_lane[u * 32u]; // (q as f32) / scale, vector.rs:135-139
-        acc = acc_step<METRIC>(acc, q[b], xv);
+        acc_step<METRIC, WITH_QQ>(acc, q[b], xv);
     }
-    return acc;
 }
 
-template <int METRIC>
-__device__ __forceinline__ float acc_chunk_i8(float acc, const uint4 v, const float *__restrict__ q,
-                                              const float *lut_lane)
+template <int METRIC, bool WITH_QQ>
+__device__ __forceinline__ void acc_chunk_i8(Acc &acc, const uint4 v, const float *__restrict__ q,
+                                             const float *lut_lane)
 {
-    acc = acc_word_i8<METRIC>(acc, v.x, q + 0, lut_lane);
-    acc = acc_word_i8<METRIC>(acc, v.y, q + 4, lut_lane);
-    acc = acc_word_i8<METRIC>(acc, v.z, q + 8, lut_lane);
-    acc = acc_word_i8<METRIC>(acc, v.w, q + 12, lut_lane);
-    return acc;
+    acc_word_i8<METRIC, WITH_QQ>(acc, v.x, q + 0, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ>(acc, v.y, q + 4, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ>(acc, v.z, q + 8, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ>(acc, v.w, q + 12, lut_lane);
+}
+
+template <bool NT>
+__device__ __forceinline__ uint4 load_chunk(const uint4 *p)
+{
+    if (NT) {
+        // streamed once per query: nontemporal (global_load_dwordx4 ... nt)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 t = __builtin_nontemporal_load((const u32x4 *)p);
+        return make_uint4(t.x, t.y, t.z, t.w);
+    }
+    return *p;
+}
+
+// one row-block: lane l walks row 64*blk + l through all d_chunks chunks
+template <int DTYPE, int METRIC, int UNROLL, bool NT, bool WITH_QQ>
+__device__ __forceinline__ void scan_rowblock(Acc &acc, const uint4 *__restrict__ p,
+                                              const float *__restrict__ q, const float *lut_lane,
+                                              uint32_t d_chunks)
+{
+    constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
+    uint32_t c = 0;
+    for (; c + UNROLL <= d_chunks; c += UNROLL) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            v[u] = load_chunk<NT>(p + (size_t)(c + u) * 64u);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (DTYPE == VFSX_I8)
+                acc_chunk_i8<METRIC, WITH_QQ>(acc, v[u], q + (c + u) * EPC, lut_lane);
+            else
+                acc_chunk_f32<METRIC, WITH_QQ>(acc, v[u], q + (c + u) * EPC);
+        }
+    }
+    for (; c < d_chunks; ++c) {
+        uint4 v = load_chunk<NT>(p + (size_t)c * 64u);
+        if (DTYPE == VFSX_I8)
+            acc_chunk_i8<METRIC, WITH_QQ>(acc, v, q + c * EPC, lut_lane);
+        else
+            acc_chunk_f32<METRIC, WITH_QQ>(acc, v, q + c * EPC);
+    }
 }
 
 // ---- the scan kernel -------------------------------------------------------------
 // grid = (n_lists, nq); block = 256 = 4 waves.  Wave w of the launch walks
 // row-blocks w, w + W, w + 2W, ... in ascending order.
-template <int DTYPE, int METRIC, typename TopK, int UNROLL>
+template <int DTYPE, int METRIC, typename TopK, int UNROLL, bool NT>
 __global__ __launch_bounds__(kBlock) void scan_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
-    const float *__restrict__ queries, const float *__restrict__ q_norms,
-    const float *__restrict__ lut, uint64_t *__restrict__ lists, uint32_t n_rows, uint32_t d_chunks,
-    uint32_t n_rowblocks, uint32_t q_stride, uint32_t k, uint32_t n_lists)
+    const float *__restrict__ queries, const float *__restrict__ lut, uint64_t *__restrict__ lists,
+    uint32_t n_rows, uint32_t d_chunks, uint32_t n_rowblocks, uint32_t q_stride, uint32_t k,
+    uint32_t n_lists)
 {
-    constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
     extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)] lists
     __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
 
@@ -269,43 +317,26 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
     const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wave;
-    float qn = 0.0f;
-    if (METRIC == VFSX_COSINE)
-        qn = q_norms[qi];
+    float qn = 0.0f; // ||q||, identical in every lane
 
     for (uint32_t blk = wave_global; blk < n_rowblocks; blk += n_waves) {
         const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
-        float acc = 0.0f;
-        uint32_t c = 0;
-        for (; c + UNROLL <= d_chunks; c += UNROLL) {
-            uint4 v[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                v[u] = p[(size_t)(c + u) * 64u];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (DTYPE == VFSX_I8)
-                    acc = acc_chunk_i8<METRIC>(acc, v[u], q + (c + u) * EPC, lut_lane);
-                else
-                    acc = acc_chunk_f32<METRIC>(acc, v[u], q + (c + u) * EPC);
-            }
-        }
-        for (; c < d_chunks; ++c) {
-            uint4 v = p[(size_t)c * 64u];
-            if (DTYPE == VFSX_I8)
-                acc = acc_chunk_i8<METRIC>(acc, v, q + c * EPC, lut_lane);
-            else
-                acc = acc_chunk_f32<METRIC>(acc, v, q + c * EPC);
+        Acc acc{0.0f, 0.0f};
+        if (METRIC == VFSX_COSINE && blk == wave_global) {
+            scan_rowblock<DTYPE, METRIC, UNROLL, NT, true>(acc, p, q, lut_lane, d_chunks);
+            qn = f_sqrt(acc.qq); // rank.rs:296
+        } else {
+            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false>(acc, p, q, lut_lane, d_chunks);
         }
         const uint32_t row = blk * 64u + lane;
         uint64_t comp = kSentinel;
         if (row < n_rows) {
             float dist;
             if (METRIC == VFSX_EUCLIDEAN) {
-                dist = f_sqrt(acc); // rank.rs:286
-            } else {                    // rank.rs:299: 1.0 - (dot / (norm_1 * norm_2))
+                dist = f_sqrt(acc.a); // rank.rs:286
+            } else {                  // rank.rs:299: 1.0 - (dot / (norm_1 * norm_2))
                 float den = f_mul(qn, row_norms[row]);
-                dist = f_sub(1.0f, f_div(acc, den));
+                dist = f_sub(1.0f, f_div(acc.a, den));
             }
             comp = ((uint64_t)dist_key(dist) << 32) | row;
         }
@@ -334,12 +365,16 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 }
 
 // ---- select: merge the per-workgroup lists of one query, emit hits ----------------
-template <typename TopK>
-__global__ __launch_bounds__(kBlock) void select_kernel(const uint64_t *__restrict__ lists,
-                                                        const uint64_t *__restrict__ ids,
-                                                        vfsx_hit *__restrict__ out, uint64_t row_base,
-                                                        uint64_t id_base, uint32_t n_lists, uint32_t k)
+// One workgroup per query.  The lists are tiny but the merge is a chain of dependent
+// HBM/L2 round trips, so it runs WAVES waves wide with 8 loads in flight per lane.
+template <typename TopK, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__restrict__ lists,
+                                                            const uint64_t *__restrict__ ids,
+                                                            vfsx_hit *__restrict__ out, uint64_t row_base,
+                                                            uint64_t id_base, uint32_t n_lists, uint32_t k)
 {
+    constexpr uint32_t BLOCK = 64u * WAVES;
+    constexpr int DEPTH = 8;
     extern __shared__ __align__(16) uint64_t dyn_lds[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -350,17 +385,18 @@ __global__ __launch_bounds__(kBlock) void select_kernel(const uint64_t *__restri
 
     TopK top;
     top.init(k, dyn_lds + wave * list_stride);
-    // wave-uniform bases; four independent loads in flight per lane
+    // wave-uniform bases
     uint64_t base = (uint64_t)wave * 64u;
-    for (; base + 3u * kBlock + 64u <= total; base += 4u * kBlock) {
-        uint64_t c0 = src[base + lane], c1 = src[base + kBlock + lane];
-        uint64_t c2 = src[base + 2u * kBlock + lane], c3 = src[base + 3u * kBlock + lane];
-        top.offer(c0);
-        top.offer(c1);
-        top.offer(c2);
-        top.offer(c3);
+    for (; base + (uint64_t)(DEPTH - 1) * BLOCK + 64u <= total; base += (uint64_t)DEPTH * BLOCK) {
+        uint64_t c[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            c[i] = src[base + (uint64_t)i * BLOCK + lane];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            top.offer(c[i]);
     }
-    for (; base < total; base += kBlock) {
+    for (; base < total; base += BLOCK) {
         uint64_t idx = base + lane;
         uint64_t c = idx < total ? src[idx] : kSentinel;
         top.offer(c);
@@ -374,10 +410,10 @@ __global__ __launch_bounds__(kBlock) void select_kernel(const uint64_t *__restri
     }
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w) {
+        for (int w = 1; w < WAVES; ++w) {
             const uint64_t *other = dyn_lds + w * list_stride;
-            for (uint32_t base = 0; base < k; base += 64) {
-                uint32_t idx = base + lane;
+            for (uint32_t b = 0; b < k; b += 64) {
+                uint32_t idx = b + lane;
                 uint64_t comp = idx < k ? other[idx] : kSentinel;
                 top.offer(comp);
             }
@@ -405,27 +441,15 @@ __global__ __launch_bounds__(kBlock) void select_kernel(const uint64_t *__restri
     }
 }
 
-// ---- query preparation: zero-padded copy + ||q|| in the reference's order ----------
-__global__ void query_prep_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
-                                  float *__restrict__ q_pad, uint32_t q_stride,
-                                  float *__restrict__ q_norms)
+// ---- query padding: zero-padded copy when dim is not a multiple of the chunk ----
+__global__ void query_pad_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
+                                 float *__restrict__ q_pad, uint32_t q_stride)
 {
-    uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq)
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)nq * q_stride)
         return;
-    const float *src = q_in + (size_t)qi * dim;
-    float s = 0.0f;
-    for (uint32_t j = 0; j < dim; ++j) { // rank.rs:296: map(x.powi(2)).sum().sqrt()
-        float v = src[j];
-        s = f_add(s, f_mul(v, v));
-        if (q_pad)
-            q_pad[(size_t)qi * q_stride + j] = v;
-    }
-    if (q_pad)
-        for (uint32_t j = dim; j < q_stride; ++j)
-            q_pad[(size_t)qi * q_stride + j] = 0.0f;
-    if (q_norms)
-        q_norms[qi] = f_sqrt(s);
+    uint32_t qi = (uint32_t)(t / q_stride), j = (uint32_t)(t % q_stride);
+    q_pad[t] = j < dim ? q_in[(size_t)qi * dim + j] : 0.0f;
 }
 
 __global__ void lut_kernel(float scale, float *__restrict__ lut)
@@ -642,54 +666,73 @@ __global__ __launch_bounds__(kBlock) void merge_hits_kernel(const vfsx_hit *__re
 
 // ---- launchers --------------------------------------------------------------------------------------
 
-template <int DTYPE, int METRIC>
-static hipError_t launch_scan_t(const ScanArgs &a, uint32_t nq, uint32_t grid_x, hipStream_t s)
+template <int DTYPE, int METRIC, int UNROLL, bool NT>
+static hipError_t launch_scan_v(const ScanArgs &a, uint32_t nq, uint32_t grid_x, hipStream_t s)
 {
     dim3 grid(grid_x, nq), block(kBlock);
     const uint32_t list_stride = a.k > 64u ? a.k : 64u;
     const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
-    constexpr int U = 8;
     if (a.k <= kMaxRegisterK) {
-        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, U>), grid, block, lds, s, a.corpus,
-                           a.row_norms, a.queries, a.q_norms, a.lut, a.lists, a.n_rows, a.d_chunks,
-                           a.n_rowblocks, a.q_stride, a.k, a.n_lists);
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT>), grid, block, lds, s, a.corpus,
+                           a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
+                           a.q_stride, a.k, a.n_lists);
     } else {
-        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, U>), grid, block, lds, s, a.corpus,
-                           a.row_norms, a.queries, a.q_norms, a.lut, a.lists, a.n_rows, a.d_chunks,
-                           a.n_rowblocks, a.q_stride, a.k, a.n_lists);
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT>), grid, block, lds, s, a.corpus,
+                           a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
+                           a.q_stride, a.k, a.n_lists);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x,
+template <int DTYPE, int METRIC>
+static hipError_t launch_scan_t(const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant, hipStream_t s)
+{
+    // variant = unroll * 2 + nt  (tuning knob; the default is chosen in vfsx_api.cpp)
+    switch (variant) {
+    case 4 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 4, false>(a, nq, grid_x, s);
+    case 4 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 4, true>(a, nq, grid_x, s);
+    case 8 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 8, true>(a, nq, grid_x, s);
+    case 8 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 8, false>(a, nq, grid_x, s);
+    case 16 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 16, false>(a, nq, grid_x, s);
+    case 16 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 16, true>(a, nq, grid_x, s);
+    default: return launch_scan_v<DTYPE, METRIC, 4, true>(a, nq, grid_x, s);
+    }
+}
+
+hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant,
                        hipStream_t s)
 {
     const bool cosine = (metric == VFSX_COSINE || metric == VFSX_SIMD_COSINE);
     if (dtype == VFSX_I8)
-        return cosine ? launch_scan_t<VFSX_I8, VFSX_COSINE>(a, nq, grid_x, s)
-                      : launch_scan_t<VFSX_I8, VFSX_EUCLIDEAN>(a, nq, grid_x, s);
-    return cosine ? launch_scan_t<VFSX_F32, VFSX_COSINE>(a, nq, grid_x, s)
-                  : launch_scan_t<VFSX_F32, VFSX_EUCLIDEAN>(a, nq, grid_x, s);
+        return cosine ? launch_scan_t<VFSX_I8, VFSX_COSINE>(a, nq, grid_x, variant, s)
+                      : launch_scan_t<VFSX_I8, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, s);
+    return cosine ? launch_scan_t<VFSX_F32, VFSX_COSINE>(a, nq, grid_x, variant, s)
+                  : launch_scan_t<VFSX_F32, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, s);
 }
 
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)
 {
     const uint32_t list_stride = a.k > 64u ? a.k : 64u;
-    const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
-    if (a.k <= kMaxRegisterK)
-        hipLaunchKernelGGL((select_kernel<WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.lists, a.ids,
+    if (a.k <= kMaxRegisterK) {
+        constexpr int W = 16;
+        const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
+        hipLaunchKernelGGL((select_kernel<WaveTopKReg, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
                            a.out, a.row_base, a.id_base, a.n_lists, a.k);
-    else
-        hipLaunchKernelGGL((select_kernel<WaveTopKLds>), dim3(nq), dim3(kBlock), lds, s, a.lists, a.ids,
+    } else {
+        constexpr int W = 4;
+        const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
+        hipLaunchKernelGGL((select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
                            a.out, a.row_base, a.id_base, a.n_lists, a.k);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_query_prep(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
-                             uint32_t q_stride, float *d_q_norms, hipStream_t s)
+hipError_t launch_query_pad(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
+                            uint32_t q_stride, hipStream_t s)
 {
-    hipLaunchKernelGGL(query_prep_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, d_queries_in, nq, dim,
-                       d_q_padded, q_stride, d_q_norms);
+    const uint64_t total = (uint64_t)nq * q_stride;
+    hipLaunchKernelGGL(query_pad_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, d_queries_in, nq,
+                       dim, d_q_padded, q_stride);
     return hipGetLastError();
 }
 

@@ -1,0 +1,104 @@
+"""Row-sharded search over the GPUs of one node: one process per GPU, each holding a
+contiguous range of the scan order; every rank produces its local top-k with the HIP
+scan, the lists are exchanged with ONE all-gather per query batch (RCCL over xGMI on
+GPUs; gloo on CPU for the tests) and merged by (distance, global row).
+
+No reference counterpart (the reference is single-process).  Shard g
+holds global rows [row_base_g, row_base_g + n_g): contiguity makes (shard, local row)
+order equal the reference's scan order, so the first-seen tie-break (rank.rs:170)
+survives the merge.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+HIT_WORDS = 6  # sizeof(vfsx_hit) / 4
+
+HIT_DTYPE = np.dtype([("dist", np.float32), ("flags", np.uint32), ("row", np.uint64), ("id", np.uint64)])
+assert HIT_DTYPE.itemsize == C.sizeof(_lib.Hit) == 24
+
+
+def split_rows(n_total: int, world: int) -> list:
+    """Contiguous row ranges: shard g = [g*ceil(N/G), min(N, (g+1)*ceil(N/G)))  (SURVEY.md 8e)."""
+    per = -(-n_total // world)
+    return [(min(n_total, g * per), min(n_total, (g + 1) * per)) for g in range(world)]
+
+
+def merge_hits_host(gathered: np.ndarray, k: int) -> np.ndarray:
+    """gathered: structured HIT_DTYPE array [n_lists, nq, k] -> [nq, k] best by (distance, row)."""
+    lib = _lib.load()
+    g = np.ascontiguousarray(gathered)
+    n_lists, nq, kk = g.shape
+    assert kk == k
+    out = np.zeros((nq, k), dtype=HIT_DTYPE)
+    _lib.check(lib.vfsx_merge_hits_host(g.ctypes.data_as(C.POINTER(_lib.Hit)), n_lists, nq, k,
+                                        out.ctypes.data_as(C.POINTER(_lib.Hit))))
+    return out
+
+
+def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[int] = None):
+    """local_hits: torch int32 tensor [nq, k, 6] (a view of vfsx_hit[nq*k]) on this
+    rank's device (cuda -> RCCL all-gather + device merge; cpu -> gloo + host merge).
+    Returns the merged [nq, k, 6] tensor (same device), identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    nq = local_hits.shape[0]
+    if world == 1:
+        return local_hits
+    flat = local_hits.contiguous().view(-1)
+    gathered = torch.empty(world * flat.numel(), dtype=local_hits.dtype, device=local_hits.device)
+    dist.all_gather_into_tensor(gathered, flat, group=group)  # rank-major: [list][query][k]
+    gathered = gathered.view((world,) + tuple(local_hits.shape))
+    if local_hits.is_cuda:
+        out = torch.empty_like(local_hits)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(local_hits.device).cuda_stream
+        dev = local_hits.device.index if device_index is None else device_index
+        _lib.check(lib.vfsx_merge_hits_device(C.c_void_p(gathered.data_ptr()), world, nq, k,
+                                              C.c_void_p(out.data_ptr()), dev, C.c_void_p(stream)))
+        return out
+    g = gathered.numpy().view(np.uint8).reshape(world, nq, k, 24).view(HIT_DTYPE).reshape(world, nq, k)
+    merged = merge_hits_host(g, k)
+    return torch.from_numpy(merged.view(np.int32).reshape(nq, k, HIT_WORDS))
+
+
+def hits_to_arrays(hits_tensor) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """[nq, k, 6] int32 tensor -> (ids[nq,k] u64, dist[nq,k] f32, count[nq])."""
+    h = hits_tensor.cpu().numpy()
+    nq, k, _ = h.shape
+    s = np.ascontiguousarray(h).view(np.uint8).reshape(nq, k, 24).view(HIT_DTYPE).reshape(nq, k)
+    valid = (s["flags"] & 1).astype(bool)
+    return s["id"].copy(), s["dist"].copy(), valid.sum(axis=1).astype(np.uint32)
+
+
+class ShardedCorpus:
+    """This rank's shard of a row-sharded corpus + the collective search."""
+
+    def __init__(self, dim: int, quantize: bool = False, scale: float = 127.0, capacity_rows: int = 0,
+                 device: int = 0, group=None):
+        from .ranker import Corpus
+        self.local = Corpus(dim, quantize=quantize, scale=scale, capacity_rows=capacity_rows, device=device)
+        self.device = device
+        self.group = group
+
+    def set_row_base(self, row_base: int) -> None:
+        self.local.set_row_base(row_base)
+
+    def search(self, d_queries, k: int, metric: int):
+        """d_queries: torch float32 cuda tensor [nq, dim]. Returns merged hits tensor [nq,k,6]."""
+        import torch
+        nq = d_queries.shape[0]
+        local = torch.empty((nq, k, HIT_WORDS), dtype=torch.int32, device=d_queries.device)
+        stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        self.local.search_device(d_queries.data_ptr(), nq, k, int(metric), local.data_ptr(), stream)
+        return exchange_and_merge(local, k, group=self.group, device_index=self.device)
+
+    def close(self) -> None:
+        self.local.close()
