@@ -148,16 +148,16 @@ def main() -> int:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if not quantize else "f32 arithmetic on i8 storage",
+        "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k,
+        "config": {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k, "storage": "i8 (QuantizedVector, dequantized on read)" if quantize else "f32",
                    "queries_per_step": qps_step, "metric_fn": ["euclidean", "cosine", "simd_euclidean",
                                                                 "simd_cosine"][metric],
                    "sharding": f"row-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
         "qps_global": round(qps_global, 3),
         "hbm_gbps_aggregate": round(qps_global * algo_bytes * world / 1e9, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args.workload, rows),
                      "kernel": "scan_kernel", "avg_kernel_ms": round(avg_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches)},
     }
@@ -170,6 +170,24 @@ def main() -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def pmc_traffic(workload, rows):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/rNN/traffic.json, written by tools_summarize_profile.py); None if
+    there is no profile for this workload/size.  PMC counters cannot be read in-process."""
+    import glob
+    if rows != WORKLOADS[workload][0]:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if workload in t:
+                return t[workload]["scan_hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def cpu_baseline(args, rows, dim, quantize, metric, k):

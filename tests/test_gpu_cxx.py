@@ -1,0 +1,16 @@
+"""GPU: the C++ Ranker mirror (vfs_amd/cxx/vfsx_ranker.hpp) through the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cxx_ranker_selftest():
+    exe = os.path.join(ROOT, "vfs_amd", "lib", "ranker_selftest")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.startswith("ok id=1 dist=3.74165")

@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py (run on the GPU box through gpurun). $1 = tag, rest = bench args
+set -e
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline "$@" > $OUT/trace.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "${@:5}" > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "${@:5}" > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -20

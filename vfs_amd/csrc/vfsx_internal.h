@@ -27,7 +27,8 @@ struct ScanArgs {
     const float *row_norms; // [n_rows] sqrt(sum x^2), sequential order (cosine only)
     const float *queries;   // [nq][q_stride] f32, zero padded to d_chunks*epc
     const float *lut;       // [256] f32 dequant table indexed by the raw byte (i8 only)
-    uint64_t *lists;        // out: [nq][n_lists][k] composite keys, ascending, kSentinel padded
+    uint64_t *lists;        // out: [nq][k][n_lists] composite keys (column-major: entry j of every
+                            // list contiguous), each list ascending, kSentinel padded
     uint32_t n_rows;
     uint32_t d_chunks;
     uint32_t n_rowblocks;
@@ -37,7 +38,7 @@ struct ScanArgs {
 };
 
 struct SelectArgs {
-    const uint64_t *lists; // [nq][n_lists][k]
+    const uint64_t *lists; // [nq][k][n_lists]
     const uint64_t *ids;   // [n_rows] or nullptr (=> id_base + local row)
     vfsx_hit *out;         // [nq][k]
     uint64_t row_base;

@@ -69,11 +69,15 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// lane l <- lane l-1 (lane 0 keeps its own value): one DPP move per dword
+// (wave_shr:1, a full-wavefront shift on the gfx9 family) instead of ds_bpermute.
 __device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v)
 {
-    uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64);
-    uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
-    return ((uint64_t)hi << 32) | lo;
+    constexpr int kDppWaveShr1 = 0x138;
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, kDppWaveShr1, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, kDppWaveShr1, 0xf, 0xf, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
 // ---- per-wave sorted top-k of composite keys ----------------------------------
@@ -116,10 +120,10 @@ struct WaveTopKReg {
     }
     // entry i (i < 64) for lane i
     __device__ __forceinline__ uint64_t mine() const { return e; }
-    __device__ __forceinline__ void store(uint64_t *dst) const
+    __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
     {
         if (lane_id() < k)
-            dst[lane_id()] = e;
+            dst[lane_id() * stride] = e;
     }
 };
 
@@ -179,10 +183,10 @@ struct WaveTopKLds {
                 insert(c);
         }
     }
-    __device__ __forceinline__ void store(uint64_t *dst) const
+    __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
     {
         for (uint32_t i = lane_id(); i < k; i += 64)
-            dst[i] = L[i];
+            dst[i * stride] = L[i];
     }
 };
 
@@ -360,13 +364,16 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                 top.offer(comp);
             }
         }
-        top.store(lists + ((size_t)qi * n_lists + blockIdx.x) * k);
+        // column-major: entry j of every list is contiguous ([q][j][list]) for the select walk
+        top.store(lists + (size_t)qi * n_lists * k + blockIdx.x, n_lists);
     }
 }
 
 // ---- select: merge the per-workgroup lists of one query, emit hits ----------------
-// One workgroup per query.  The lists are tiny but the merge is a chain of dependent
-// HBM/L2 round trips, so it runs WAVES waves wide with 8 loads in flight per lane.
+// One workgroup per query.  Lists arrive column-major ([j][list], each list ascending).
+// A lane owns one list and walks it only while its entries still beat the wave's
+// current k-th best (tau only shrinks, entries only grow): with random data that is
+// 1-2 columns, i.e. 1-2 HBM/L2 round trips, instead of reading and offering everything.
 template <typename TopK, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__restrict__ lists,
                                                             const uint64_t *__restrict__ ids,
@@ -374,32 +381,30 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
                                                             uint64_t id_base, uint32_t n_lists, uint32_t k)
 {
     constexpr uint32_t BLOCK = 64u * WAVES;
-    constexpr int DEPTH = 8;
     extern __shared__ __align__(16) uint64_t dyn_lds[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t qi = blockIdx.x;
     const uint32_t list_stride = k > 64u ? k : 64u;
     const uint64_t *__restrict__ src = lists + (size_t)qi * n_lists * k;
-    const uint64_t total = (uint64_t)n_lists * k;
 
     TopK top;
     top.init(k, dyn_lds + wave * list_stride);
-    // wave-uniform bases
-    uint64_t base = (uint64_t)wave * 64u;
-    for (; base + (uint64_t)(DEPTH - 1) * BLOCK + 64u <= total; base += (uint64_t)DEPTH * BLOCK) {
-        uint64_t c[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            c[i] = src[base + (uint64_t)i * BLOCK + lane];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            top.offer(c[i]);
-    }
-    for (; base < total; base += BLOCK) {
-        uint64_t idx = base + lane;
-        uint64_t c = idx < total ? src[idx] : kSentinel;
-        top.offer(c);
+    for (uint32_t lbase = wave * 64u; lbase < n_lists; lbase += BLOCK) { // wave-uniform
+        const uint32_t list = lbase + lane;
+        bool alive = list < n_lists;
+        for (uint32_t j = 0; j < k; j += 2) {
+            // two columns per round trip
+            uint64_t c0 = alive ? src[(size_t)j * n_lists + list] : kSentinel;
+            uint64_t c1 = (alive && j + 1 < k) ? src[(size_t)(j + 1) * n_lists + list] : kSentinel;
+            alive = alive && (c1 < top.tau);
+            if (__ballot(c0 < top.tau) == 0)
+                break;
+            top.offer(c0);
+            top.offer(c1);
+            if (__ballot(alive) == 0)
+                break;
+        }
     }
 
     uint64_t *mine = dyn_lds + wave * list_stride;
@@ -410,14 +415,17 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
     }
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < WAVES; ++w) {
-            const uint64_t *other = dyn_lds + w * list_stride;
-            for (uint32_t b = 0; b < k; b += 64) {
-                uint32_t idx = b + lane;
-                uint64_t comp = idx < k ? other[idx] : kSentinel;
-                top.offer(comp);
-            }
+        // lane w walks wave w's (ascending) list the same way
+        bool alive = lane >= 1 && lane < (uint32_t)WAVES;
+        const uint64_t *other = dyn_lds + (alive ? lane : 0u) * list_stride;
+        for (uint32_t j = 0; j < k; ++j) {
+            uint64_t c = alive ? other[j] : kSentinel;
+            if (__ballot(c < top.tau) == 0)
+                break;
+            top.offer(c);
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
         top.store(mine);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
