@@ -47,6 +47,9 @@ def main() -> int:
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--queries-per-step", type=int, default=16)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--mode", default="single", choices=["single", "batch"],
+                    help="single: one scan launch per query (the headline); batch: one call per step, "
+                         "queries share corpus passes (8 per pass)")
     ap.add_argument("--rows", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
@@ -70,12 +73,25 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (vfs_amd has no CPU path)", file=sys.stderr)
         return 2
+    # one rank per GPU; the modulo only matters when rehearsing N ranks on fewer GPUs
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VFSX_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
+    debug = bool(os.environ.get("VFSX_BENCH_DEBUG"))
+
+    def dbg(msg):
+        if debug:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    dbg("process group up")
     rows, dim, quantize, metric, label = WORKLOADS[args.workload]
     if args.rows:
         rows = args.rows
@@ -87,6 +103,7 @@ def main() -> int:
     corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
     corpus.set_row_base(rank * rows)
 
+    dbg("corpus filled")
     n_q = (args.steps + args.warmup) * qps_step
     q_host = synth.rows_f32(synth.QUERY_SEED, 0, n_q, dim)
     d_q = torch.from_numpy(q_host).to(dev)
@@ -96,8 +113,11 @@ def main() -> int:
     def run_step(step_idx: int) -> None:
         stream = torch.cuda.current_stream().cuda_stream
         base = step_idx * qps_step
-        for j in range(qps_step):  # one scan launch per query: "single-query scan"
-            corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
+        if args.mode == "batch":
+            corpus.search_device(d_q[base].data_ptr(), qps_step, k, metric, d_local.data_ptr(), stream)
+        else:
+            for j in range(qps_step):  # one scan launch per query: "single-query scan"
+                corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
         if world > 1:  # ONE all-gather per step (queries_per_step x k x 24 B per rank), device merge
             sharded.exchange_and_merge(d_local, k, device_index=local_rank)
 
@@ -109,27 +129,35 @@ def main() -> int:
 
     for s in range(args.warmup):
         run_step(s)
+        dbg(f"warmup step {s} enqueued")
     fence()
+    dbg("warmup done")
     t0 = time.perf_counter()
     for s in range(args.steps):
         run_step(args.warmup + s)
     fence()
     elapsed = time.perf_counter() - t0
+    dbg("timed region done")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    dbg("max over ranks done")
 
     # roofline leg: same launches, scan kernel bracketed by HIP events on its own stream
     corpus.set_profiling(True)
     for s in range(min(args.steps, 8)):
         base = (args.warmup + s) * qps_step
         stream = torch.cuda.current_stream().cuda_stream
-        for j in range(qps_step):
-            corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
+        if args.mode == "batch":
+            corpus.search_device(d_q[base].data_ptr(), qps_step, k, metric, d_local.data_ptr(), stream)
+        else:
+            for j in range(qps_step):
+                corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
     torch.cuda.synchronize()
     scan_ms, scan_launches = corpus.scan_time_ms()
     corpus.set_profiling(False)
+    dbg("roofline leg done")
     avg_ms = scan_ms / max(scan_launches, 1)
     algo_bytes = rows * dim * elem  # N*d*sizeof(elem) per query, ids/norms excluded
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
@@ -151,7 +179,7 @@ def main() -> int:
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k, "storage": "i8 (QuantizedVector, dequantized on read)" if quantize else "f32",
-                   "queries_per_step": qps_step, "metric_fn": ["euclidean", "cosine", "simd_euclidean",
+                   "queries_per_step": qps_step, "mode": args.mode, "metric_fn": ["euclidean", "cosine", "simd_euclidean",
                                                                 "simd_cosine"][metric],
                    "sharding": f"row-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
         "qps_global": round(qps_global, 3),
@@ -167,7 +195,9 @@ def main() -> int:
     if rank == 0:
         print(json.dumps(out), flush=True)
     corpus.close()
+    dbg("closed")
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     return 0
 

@@ -142,3 +142,29 @@ def test_nan_sorts_last_documented_deviation():
     assert cnt[0] == 5 and ids[0].tolist() == [1, 5, 3, 2, 4]
     assert np.isnan(dist[0, 3:]).all() and not np.isnan(dist[0, :3]).any()
     c.close()
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+@pytest.mark.parametrize("nq", [2, 3, 4, 5, 8, 17])
+def test_multi_query_passes_bit_exact(oracle, quantize, nq):
+    """nq > 1: 2/4/8 queries share one pass over the corpus; every query's result must
+    equal its own single-query result (ragged last group included)."""
+    import vfs_amd
+    rng = np.random.default_rng(nq * 3 + quantize)
+    n, d = 7000, 72 if not quantize else 40
+    if quantize:
+        rows = rng.integers(-128, 128, (n, d), dtype=np.int8)
+        rows[np.abs(rows).sum(axis=1) == 0, 0] = 1
+    else:
+        rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    c.append(rows)
+    for metric in (0, 1):
+        for k in (10, 100):
+            ids, dist, cnt = c.search_batch(queries, k, metric)
+            for qi in range(nq):
+                oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k)
+                assert cnt[qi] == k and (ids[qi] == oi).all(), (metric, k, qi)
+                assert (bits(dist[qi]) == bits(od)).all(), (metric, k, qi)
+    c.close()

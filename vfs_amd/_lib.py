@@ -62,6 +62,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(vfs_amd has no CPU fallback)")
+    # PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's).  Two HIP
+    # runtimes in one process cannot both own the GPU ("No HIP GPUs are available"), so in
+    # a Python host let torch's copy load first; libvfsx.so then binds to that one.
+    if not os.environ.get("VFSX_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp, u64p, f32p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     hitp = C.POINTER(Hit)

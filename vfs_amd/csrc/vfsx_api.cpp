@@ -138,6 +138,7 @@ struct vfsx_corpus {
     DeviceBuf<uint8_t> row_out;
     uint32_t max_blocks = 0;
     int unroll_override = 0; // 0 = auto
+    uint64_t nq_per_pass_max = 8;
     int nt_override = 2;     // 2 = auto
 
     // profiling
@@ -344,6 +345,20 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     if (unroll != 4 && unroll != 8 && unroll != 16)
         unroll = c->dtype == VFSX_I8 ? 4 : (c->d_chunks >= 64 ? 16 : 8);
     const int scan_variant = unroll * 2 + nt;
+    // queries per corpus pass: as many as the batch offers (max 8), while the workgroup's
+    // LDS (lists + staged queries [+ 32 KiB LUT for int8]) stays within 64 KiB
+    int nq_per_pass = 1;
+    {
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(8, c->nq_per_pass_max);
+        const size_t lds_static = c->dtype == VFSX_I8 ? 32768 : 16;
+        for (int cand : {8, 4, 2}) {
+            if ((uint32_t)cand <= cap && nq >= (uint32_t)cand &&
+                vfsx::scan_lds_bytes(k, cand, q_stride) + lds_static <= 65536) {
+                nq_per_pass = cand;
+                break;
+            }
+        }
+    }
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + 3u) / 4u, c->max_blocks);
     // queries per launch: bounded by gridDim.y and by a 256 MiB list workspace
     uint32_t q_per_launch = nq;
@@ -370,7 +385,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
             a.n_lists = grid_x;
             size_t slot = 0;
             prof_begin(c, s, slot);
-            HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, s));
+            HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
             prof_end(c, s, slot);
         }
         SelectArgs sa{};
@@ -455,6 +470,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         // search_device_impl together with the nontemporal hint.
         c->unroll_override = (int)env_u64("VFSX_SCAN_UNROLL", 0);
         c->nt_override = (int)env_u64("VFSX_SCAN_NT", 2);
+        c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)

@@ -48,8 +48,11 @@ struct SelectArgs {
 };
 
 // launchers (vfsx_kernels.hip). All enqueue on `s` and return the launch status.
+// nq_per_pass in {1,2,4,8}: queries that share one pass over the corpus (one workgroup column)
 hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant,
-                       hipStream_t s);
+                       int nq_per_pass, hipStream_t s);
+// dynamic LDS the scan kernel needs (the i8 kernels add 32 KiB of static LDS for the LUT)
+size_t scan_lds_bytes(uint32_t k, int nq_per_pass, uint32_t q_stride);
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s);
 hipError_t launch_query_pad(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
                             uint32_t q_stride, hipStream_t s);

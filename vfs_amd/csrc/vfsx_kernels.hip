@@ -215,37 +215,53 @@ __device__ __forceinline__ void acc_step(Acc &acc, float qv, float xv)
     }
 }
 
-template <int METRIC, bool WITH_QQ>
-__device__ __forceinline__ void acc_chunk_f32(Acc &acc, const uint4 v, const float *__restrict__ q)
+// NQ queries share one pass over the row: element x_j is loaded once and folded into
+// NQ independent accumulators.  `q` points at query 0's chunk, `qs` is the stride
+// (floats) to the next query.  NQ == 1: q is global + wave-uniform -> s_load/SGPR.
+// NQ > 1: q is the workgroup's LDS copy; every lane reads the same address (broadcast).
+template <int METRIC, bool WITH_QQ, int NQ>
+__device__ __forceinline__ void acc_chunk_f32(Acc (&acc)[NQ], const uint4 v, const float *__restrict__ q,
+                                              uint32_t qs)
 {
-    acc_step<METRIC, WITH_QQ>(acc, q[0], __uint_as_float(v.x));
-    acc_step<METRIC, WITH_QQ>(acc, q[1], __uint_as_float(v.y));
-    acc_step<METRIC, WITH_QQ>(acc, q[2], __uint_as_float(v.z));
-    acc_step<METRIC, WITH_QQ>(acc, q[3], __uint_as_float(v.w));
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float4 qv = *(const float4 *)(q + (size_t)n * qs);
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.x, __uint_as_float(v.x));
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.y, __uint_as_float(v.y));
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.z, __uint_as_float(v.z));
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.w, __uint_as_float(v.w));
+    }
 }
 
 // i8: the byte indexes a per-bank replica of the 256-entry dequant table in LDS
 // (lut_s[u * 32 + (lane & 31)]): lane l always hits bank l & 31 -> conflict free.
-template <int METRIC, bool WITH_QQ>
-__device__ __forceinline__ void acc_word_i8(Acc &acc, uint32_t w, const float *__restrict__ q,
+// Dequantized once per element, shared by the NQ queries.
+template <int METRIC, bool WITH_QQ, int NQ>
+__device__ __forceinline__ void acc_word_i8(Acc (&acc)[NQ], uint32_t w, const float *__restrict__ q, uint32_t qs,
                                             const float *lut_lane)
 {
+    float xv[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        uint32_t u = (w >> (8 * b)) & 0xffu;
-        float xv = lut_lane[u * 32u]; // (q as f32) / scale, vector.rs:135-139
-        acc_step<METRIC, WITH_QQ>(acc, q[b], xv);
+    for (int b = 0; b < 4; ++b)
+        xv[b] = lut_lane[((w >> (8 * b)) & 0xffu) * 32u]; // (q as f32) / scale, vector.rs:135-139
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float4 qv = *(const float4 *)(q + (size_t)n * qs);
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.x, xv[0]);
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.y, xv[1]);
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.z, xv[2]);
+        acc_step<METRIC, WITH_QQ>(acc[n], qv.w, xv[3]);
     }
 }
 
-template <int METRIC, bool WITH_QQ>
-__device__ __forceinline__ void acc_chunk_i8(Acc &acc, const uint4 v, const float *__restrict__ q,
-                                             const float *lut_lane)
+template <int METRIC, bool WITH_QQ, int NQ>
+__device__ __forceinline__ void acc_chunk_i8(Acc (&acc)[NQ], const uint4 v, const float *__restrict__ q,
+                                             uint32_t qs, const float *lut_lane)
 {
-    acc_word_i8<METRIC, WITH_QQ>(acc, v.x, q + 0, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ>(acc, v.y, q + 4, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ>(acc, v.z, q + 8, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ>(acc, v.w, q + 12, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.x, q + 0, qs, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.y, q + 4, qs, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.z, q + 8, qs, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.w, q + 12, qs, lut_lane);
 }
 
 template <bool NT>
@@ -261,9 +277,9 @@ __device__ __forceinline__ uint4 load_chunk(const uint4 *p)
 }
 
 // one row-block: lane l walks row 64*blk + l through all d_chunks chunks
-template <int DTYPE, int METRIC, int UNROLL, bool NT, bool WITH_QQ>
-__device__ __forceinline__ void scan_rowblock(Acc &acc, const uint4 *__restrict__ p,
-                                              const float *__restrict__ q, const float *lut_lane,
+template <int DTYPE, int METRIC, int UNROLL, bool NT, bool WITH_QQ, int NQ>
+__device__ __forceinline__ void scan_rowblock(Acc (&acc)[NQ], const uint4 *__restrict__ p,
+                                              const float *__restrict__ q, uint32_t qs, const float *lut_lane,
                                               uint32_t d_chunks)
 {
     constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
@@ -276,96 +292,137 @@ __device__ __forceinline__ void scan_rowblock(Acc &acc, const uint4 *__restrict_
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (DTYPE == VFSX_I8)
-                acc_chunk_i8<METRIC, WITH_QQ>(acc, v[u], q + (c + u) * EPC, lut_lane);
+                acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs, lut_lane);
             else
-                acc_chunk_f32<METRIC, WITH_QQ>(acc, v[u], q + (c + u) * EPC);
+                acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs);
         }
     }
     for (; c < d_chunks; ++c) {
         uint4 v = load_chunk<NT>(p + (size_t)c * 64u);
         if (DTYPE == VFSX_I8)
-            acc_chunk_i8<METRIC, WITH_QQ>(acc, v, q + c * EPC, lut_lane);
+            acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs, lut_lane);
         else
-            acc_chunk_f32<METRIC, WITH_QQ>(acc, v, q + c * EPC);
+            acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs);
     }
 }
 
 // ---- the scan kernel -------------------------------------------------------------
-// grid = (n_lists, nq); block = 256 = 4 waves.  Wave w of the launch walks
-// row-blocks w, w + W, w + 2W, ... in ascending order.
-template <int DTYPE, int METRIC, typename TopK, int UNROLL, bool NT>
+// grid = (n_lists, ceil(nq / NQ)); block = 256 = 4 waves.  Wave w of the launch walks
+// row-blocks w, w + W, w + 2W, ... in ascending order, NQ queries at a time.
+// dynamic LDS: [4 waves][NQ][max(k,64)] u64 lists, then (NQ > 1) [NQ][q_stride] f32 queries.
+template <int DTYPE, int METRIC, typename TopK, int UNROLL, bool NT, int NQ>
 __global__ __launch_bounds__(kBlock) void scan_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
     const float *__restrict__ queries, const float *__restrict__ lut, uint64_t *__restrict__ lists,
     uint32_t n_rows, uint32_t d_chunks, uint32_t n_rowblocks, uint32_t q_stride, uint32_t k,
-    uint32_t n_lists)
+    uint32_t n_lists, uint32_t nq)
 {
-    extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)] lists
+    extern __shared__ __align__(16) uint64_t dyn_lds[];
     __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
 
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t qi = blockIdx.y;
+    const uint32_t q0 = blockIdx.y * NQ; // first query of this group
     const uint32_t list_stride = k > 64u ? k : 64u;
 
     if (DTYPE == VFSX_I8) {
         for (uint32_t i = threadIdx.x; i < 256u * 32u; i += kBlock)
             lut_s[i] = lut[i >> 5];
-        __syncthreads();
     }
     const float *lut_lane = lut_s + (lane & 31u);
 
-    const float *__restrict__ q = queries + (size_t)qi * q_stride;
-    TopK top;
-    top.init(k, dyn_lds + wave * list_stride);
+    // query source
+    const float *__restrict__ q;
+    uint32_t qs;
+    if (NQ == 1) {
+        q = queries + (size_t)q0 * q_stride;
+        qs = 0;
+    } else {
+        float *q_s = (float *)(dyn_lds + (size_t)kWavesPerBlock * NQ * list_stride);
+        for (uint32_t i = threadIdx.x; i < NQ * q_stride; i += kBlock) {
+            uint32_t n = i / q_stride, j = i - n * q_stride;
+            uint32_t qi = q0 + n < nq ? q0 + n : nq - 1; // ragged last group: repeat the last query
+            q_s[i] = queries[(size_t)qi * q_stride + j];
+        }
+        q = q_s;
+        qs = q_stride;
+    }
+    if (DTYPE == VFSX_I8 || NQ > 1)
+        __syncthreads();
+
+    TopK top[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        top[n].init(k, dyn_lds + ((size_t)wave * NQ + n) * list_stride);
 
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
     const uint32_t wave_global = blockIdx.x * kWavesPerBlock + wave;
-    float qn = 0.0f; // ||q||, identical in every lane
+    float qn[NQ]; // ||q||, identical in every lane
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        qn[n] = 0.0f;
 
     for (uint32_t blk = wave_global; blk < n_rowblocks; blk += n_waves) {
         const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
-        Acc acc{0.0f, 0.0f};
+        Acc acc[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+            acc[n] = Acc{0.0f, 0.0f};
         if (METRIC == VFSX_COSINE && blk == wave_global) {
-            scan_rowblock<DTYPE, METRIC, UNROLL, NT, true>(acc, p, q, lut_lane, d_chunks);
-            qn = f_sqrt(acc.qq); // rank.rs:296
+            scan_rowblock<DTYPE, METRIC, UNROLL, NT, true, NQ>(acc, p, q, qs, lut_lane, d_chunks);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+                qn[n] = f_sqrt(acc[n].qq); // rank.rs:296
         } else {
-            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false>(acc, p, q, lut_lane, d_chunks);
+            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false, NQ>(acc, p, q, qs, lut_lane, d_chunks);
         }
         const uint32_t row = blk * 64u + lane;
-        uint64_t comp = kSentinel;
-        if (row < n_rows) {
-            float dist;
-            if (METRIC == VFSX_EUCLIDEAN) {
-                dist = f_sqrt(acc.a); // rank.rs:286
-            } else {                  // rank.rs:299: 1.0 - (dot / (norm_1 * norm_2))
-                float den = f_mul(qn, row_norms[row]);
-                dist = f_sub(1.0f, f_div(acc.a, den));
+        float rn = 0.0f;
+        if (METRIC == VFSX_COSINE && row < n_rows)
+            rn = row_norms[row];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            uint64_t comp = kSentinel;
+            if (row < n_rows) {
+                float dist;
+                if (METRIC == VFSX_EUCLIDEAN) {
+                    dist = f_sqrt(acc[n].a); // rank.rs:286
+                } else {                     // rank.rs:299: 1.0 - (dot / (norm_1 * norm_2))
+                    float den = f_mul(qn[n], rn);
+                    dist = f_sub(1.0f, f_div(acc[n].a, den));
+                }
+                comp = ((uint64_t)dist_key(dist) << 32) | row;
             }
-            comp = ((uint64_t)dist_key(dist) << 32) | row;
+            top[n].offer(comp);
         }
-        top.offer(comp);
     }
 
-    // fold the 4 waves' lists into wave 0's, then one list per workgroup to HBM
-    uint64_t *mine = dyn_lds + wave * list_stride;
+    // fold the 4 waves' lists into wave 0's, then one list per workgroup and query to HBM
     __syncthreads(); // (TopKLds: lists already live there; Reg: publish them)
     if (TopK::kInRegisters) {
-        mine[lane] = kSentinel;
-        top.store(mine);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            uint64_t *mine = dyn_lds + ((size_t)wave * NQ + n) * list_stride;
+            mine[lane] = kSentinel;
+            top[n].store(mine);
+        }
     }
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w) {
-            const uint64_t *other = dyn_lds + w * list_stride;
-            for (uint32_t base = 0; base < k; base += 64) {
-                uint32_t idx = base + lane;
-                uint64_t comp = idx < k ? other[idx] : kSentinel;
-                top.offer(comp);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            for (int w = 1; w < kWavesPerBlock; ++w) {
+                const uint64_t *other = dyn_lds + ((size_t)w * NQ + n) * list_stride;
+                for (uint32_t base = 0; base < k; base += 64) {
+                    uint32_t idx = base + lane;
+                    uint64_t comp = idx < k ? other[idx] : kSentinel;
+                    top[n].offer(comp);
+                }
             }
+            // column-major: entry j of every list is contiguous ([q][j][list]) for the select walk
+            if (q0 + n < nq)
+                top[n].store(lists + (size_t)(q0 + n) * n_lists * k + blockIdx.x, n_lists);
         }
-        // column-major: entry j of every list is contiguous ([q][j][list]) for the select walk
-        top.store(lists + (size_t)qi * n_lists * k + blockIdx.x, n_lists);
     }
 }
 
@@ -674,48 +731,69 @@ __global__ __launch_bounds__(kBlock) void merge_hits_kernel(const vfsx_hit *__re
 
 // ---- launchers --------------------------------------------------------------------------------------
 
-template <int DTYPE, int METRIC, int UNROLL, bool NT>
+size_t scan_lds_bytes(uint32_t k, int nq_per_pass, uint32_t q_stride);
+
+template <int DTYPE, int METRIC, int UNROLL, bool NT, int NQ>
 static hipError_t launch_scan_v(const ScanArgs &a, uint32_t nq, uint32_t grid_x, hipStream_t s)
 {
-    dim3 grid(grid_x, nq), block(kBlock);
-    const uint32_t list_stride = a.k > 64u ? a.k : 64u;
-    const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
+    dim3 grid(grid_x, (nq + NQ - 1) / NQ), block(kBlock);
+    const size_t lds = scan_lds_bytes(a.k, NQ, a.q_stride);
     if (a.k <= kMaxRegisterK) {
-        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT>), grid, block, lds, s, a.corpus,
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT, NQ>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists);
+                           a.q_stride, a.k, a.n_lists, nq);
     } else {
-        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT>), grid, block, lds, s, a.corpus,
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT, NQ>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists);
+                           a.q_stride, a.k, a.n_lists, nq);
     }
     return hipGetLastError();
 }
 
 template <int DTYPE, int METRIC>
-static hipError_t launch_scan_t(const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant, hipStream_t s)
+static hipError_t launch_scan_t(const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant, int nq_per_pass,
+                                hipStream_t s)
 {
-    // variant = unroll * 2 + nt  (tuning knob; the default is chosen in vfsx_api.cpp)
+    // multi-query passes: unroll 4, nontemporal per `variant & 1`
+    const bool nt = variant & 1;
+    if (nq_per_pass == 8)
+        return nt ? launch_scan_v<DTYPE, METRIC, 4, true, 8>(a, nq, grid_x, s)
+                  : launch_scan_v<DTYPE, METRIC, 4, false, 8>(a, nq, grid_x, s);
+    if (nq_per_pass == 4)
+        return nt ? launch_scan_v<DTYPE, METRIC, 4, true, 4>(a, nq, grid_x, s)
+                  : launch_scan_v<DTYPE, METRIC, 4, false, 4>(a, nq, grid_x, s);
+    if (nq_per_pass == 2)
+        return nt ? launch_scan_v<DTYPE, METRIC, 4, true, 2>(a, nq, grid_x, s)
+                  : launch_scan_v<DTYPE, METRIC, 4, false, 2>(a, nq, grid_x, s);
+    // single query: variant = unroll * 2 + nt  (tuning knob; the default is chosen in vfsx_api.cpp)
     switch (variant) {
-    case 4 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 4, false>(a, nq, grid_x, s);
-    case 4 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 4, true>(a, nq, grid_x, s);
-    case 8 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 8, true>(a, nq, grid_x, s);
-    case 8 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 8, false>(a, nq, grid_x, s);
-    case 16 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 16, false>(a, nq, grid_x, s);
-    case 16 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 16, true>(a, nq, grid_x, s);
-    default: return launch_scan_v<DTYPE, METRIC, 4, true>(a, nq, grid_x, s);
+    case 4 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 4, false, 1>(a, nq, grid_x, s);
+    case 8 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 8, true, 1>(a, nq, grid_x, s);
+    case 8 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 8, false, 1>(a, nq, grid_x, s);
+    case 16 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 16, false, 1>(a, nq, grid_x, s);
+    case 16 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 16, true, 1>(a, nq, grid_x, s);
+    default: return launch_scan_v<DTYPE, METRIC, 4, true, 1>(a, nq, grid_x, s);
     }
 }
 
+size_t scan_lds_bytes(uint32_t k, int nq_per_pass, uint32_t q_stride)
+{
+    const uint32_t list_stride = k > 64u ? k : 64u;
+    size_t lds = (size_t)kWavesPerBlock * nq_per_pass * list_stride * sizeof(uint64_t);
+    if (nq_per_pass > 1)
+        lds += (size_t)nq_per_pass * q_stride * sizeof(float);
+    return lds;
+}
+
 hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, int variant,
-                       hipStream_t s)
+                       int nq_per_pass, hipStream_t s)
 {
     const bool cosine = (metric == VFSX_COSINE || metric == VFSX_SIMD_COSINE);
     if (dtype == VFSX_I8)
-        return cosine ? launch_scan_t<VFSX_I8, VFSX_COSINE>(a, nq, grid_x, variant, s)
-                      : launch_scan_t<VFSX_I8, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, s);
-    return cosine ? launch_scan_t<VFSX_F32, VFSX_COSINE>(a, nq, grid_x, variant, s)
-                  : launch_scan_t<VFSX_F32, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, s);
+        return cosine ? launch_scan_t<VFSX_I8, VFSX_COSINE>(a, nq, grid_x, variant, nq_per_pass, s)
+                      : launch_scan_t<VFSX_I8, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, nq_per_pass, s);
+    return cosine ? launch_scan_t<VFSX_F32, VFSX_COSINE>(a, nq, grid_x, variant, nq_per_pass, s)
+                  : launch_scan_t<VFSX_F32, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, nq_per_pass, s);
 }
 
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)

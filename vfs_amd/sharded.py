@@ -52,11 +52,15 @@ def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[in
     nq = local_hits.shape[0]
     if world == 1:
         return local_hits
-    flat = local_hits.contiguous().view(-1)
-    gathered = torch.empty(world * flat.numel(), dtype=local_hits.dtype, device=local_hits.device)
+    # RCCL moves device tensors; any other backend (gloo, used for CPU tests and
+    # rehearsals) gets host tensors and the host merge.
+    on_device = local_hits.is_cuda and dist.get_backend(group) == "nccl"
+    src = local_hits if on_device or not local_hits.is_cuda else local_hits.cpu()
+    flat = src.contiguous().view(-1)
+    gathered = torch.empty(world * flat.numel(), dtype=src.dtype, device=src.device)
     dist.all_gather_into_tensor(gathered, flat, group=group)  # rank-major: [list][query][k]
     gathered = gathered.view((world,) + tuple(local_hits.shape))
-    if local_hits.is_cuda:
+    if on_device:
         out = torch.empty_like(local_hits)
         lib = _lib.load()
         stream = torch.cuda.current_stream(local_hits.device).cuda_stream
@@ -66,7 +70,8 @@ def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[in
         return out
     g = gathered.numpy().view(np.uint8).reshape(world, nq, k, 24).view(HIT_DTYPE).reshape(world, nq, k)
     merged = merge_hits_host(g, k)
-    return torch.from_numpy(merged.view(np.int32).reshape(nq, k, HIT_WORDS))
+    out = torch.from_numpy(merged.view(np.int32).reshape(nq, k, HIT_WORDS))
+    return out.to(local_hits.device) if local_hits.is_cuda else out
 
 
 def hits_to_arrays(hits_tensor) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
