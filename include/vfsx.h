@@ -204,8 +204,22 @@ int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint
                          vfsx_hit *out);
 
 /*
+ * Many-query batches on the matrix cores (no reference counterpart: the reference has no
+ * multi-query API, rank.rs:90; a batch is defined as the single-query result per query).
+ * Enabling builds a bf16 mirror of the corpus (+2 bytes per element of HBM).  Afterwards
+ * vfsx_search / vfsx_search_device route Cosine batches of >= 64 queries with k <= 64
+ * through Q.X^T on MFMA + an exact sequential re-score of the surviving candidates + a
+ * rigorous bound check, and re-run the exact scan for any query the check cannot clear:
+ * the results stay bit-identical to the single-query scan.  On this path
+ * vfsx_search_device synchronises `stream` once (to read the per-query check flags).
+ */
+int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable);
+/* Queries answered through the MFMA path and how many of them fell back to the exact scan. */
+int vfsx_corpus_mfma_stats(vfsx_corpus *c, uint64_t *queries, uint64_t *fallbacks, int reset);
+
+/*
  * Profiling aid: when enabled, vfsx_search / vfsx_search_device bracket the scan
- * kernel with HIP events on the stream it is launched on; vfsx_corpus_scan_time_ms
+ * kernel (the prefilter GEMM on the MFMA path) with HIP events on the stream it is launched on; vfsx_corpus_scan_time_ms
  * returns the accumulated kernel milliseconds and launch count since the last reset
  * (synchronises on the last event).
  */

@@ -1,0 +1,111 @@
+"""GPU: many-query Cosine batches on the matrix cores (vfsx_mfma.hip) must return exactly
+what the single-query scan returns -- ids identical and distances bit-exact -- because the
+MFMA scores only pre-filter: survivors are re-scored in the reference's sequential order and
+a bound check sends every doubtful query back to the exact scan."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _compare(c, queries, k, oracle=None, rows=None):
+    """MFMA batch result vs the exact scan of the same corpus (and vs the oracle on a sample)."""
+    c.enable_mfma(True)
+    c.mfma_stats(reset=True)
+    ids_m, dist_m, cnt_m = c.search_batch(queries, k, 1)
+    nq_m, fb = c.mfma_stats()
+    assert nq_m == len(queries), "the batch did not take the MFMA path"
+    c.enable_mfma(False)
+    ids_e, dist_e, cnt_e = c.search_batch(queries, k, 1)
+    assert (cnt_m == cnt_e).all()
+    assert (ids_m == ids_e).all()
+    assert (bits(dist_m) == bits(dist_e)).all()
+    if oracle is not None:
+        for qi in range(0, len(queries), max(1, len(queries) // 5)):
+            oi, od, _ = oracle.topk_scan(rows, queries[qi], 1, k)
+            assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
+    return fb
+
+
+@pytest.mark.parametrize("d,n,k", [(128, 40000, 10), (100, 33333, 5), (768, 20000, 10), (64, 70000, 40)])
+def test_mfma_batch_equals_exact_f32(oracle, d, n, k):
+    import vfs_amd
+    rng = np.random.default_rng(d + n)
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (200, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    fb = _compare(c, queries, k, oracle, rows)
+    assert fb <= 100  # the check may send queries back; the result must not change either way
+    c.close()
+
+
+def test_mfma_batch_equals_exact_int8(oracle):
+    import vfs_amd
+    rng = np.random.default_rng(77)
+    n, d = 50000, 96
+    rows = rng.integers(-128, 128, (n, d), dtype=np.int8)
+    queries = rng.uniform(-1, 1, (130, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=True)
+    c.append(rows)
+    _compare(c, queries, 10, oracle, rows)
+    c.close()
+
+
+def test_mfma_clustered_corpus_forces_fallbacks(oracle):
+    """Near-duplicate rows packed next to each other: many rows of one candidate list sit above
+    the safety margin, the check must flag those queries, and the exact scan must answer them."""
+    import vfs_amd
+    rng = np.random.default_rng(5)
+    n, d = 30000, 64
+    centers = rng.uniform(-1, 1, (30, d)).astype(np.float32)
+    rows = np.repeat(centers, n // 30, axis=0) + rng.normal(0, 1e-3, (n, d)).astype(np.float32)
+    rows = rows.astype(np.float32)
+    queries = (centers[rng.integers(0, 30, 128)] + rng.normal(0, 1e-3, (128, d))).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    fb = _compare(c, queries, 10, oracle, rows)
+    assert fb > 0
+    c.close()
+
+
+def test_mfma_zero_norm_rows_disable_the_path():
+    import vfs_amd
+    rng = np.random.default_rng(6)
+    n, d = 20000, 64
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    rows[1234] = 0.0  # cosine distance NaN in the reference (rank.rs:299)
+    queries = rng.uniform(-1, 1, (128, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    c.enable_mfma(True)
+    ids_m, dist_m, _ = c.search_batch(queries, 10, 1)
+    assert c.mfma_stats()[0] == 0  # mirror flagged bad -> exact scan
+    c.enable_mfma(False)
+    ids_e, dist_e, _ = c.search_batch(queries, 10, 1)
+    assert (ids_m == ids_e).all() and (bits(dist_m) == bits(dist_e)).all()
+    c.close()
+
+
+def test_mfma_bad_queries_and_append_after_enable(oracle):
+    import vfs_amd
+    rng = np.random.default_rng(8)
+    n, d = 25000, 80
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (150, d)).astype(np.float32)
+    queries[3] = 0.0  # zero query: NaN distances everywhere, handled by the exact scan
+    c = vfs_amd.Corpus(d)
+    c.append(rows[:20000])
+    c.enable_mfma(True)
+    c.append(rows[20000:])  # mirror goes stale and is rebuilt
+    c.mfma_stats(reset=True)
+    ids_m, dist_m, cnt = c.search_batch(queries, 10, 1)
+    assert c.mfma_stats()[0] == 150 and c.mfma_stats()[1] >= 1
+    for qi in (0, 1, 2, 77, 149):
+        oi, od, _ = oracle.topk_scan(rows, queries[qi], 1, 10)
+        assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
+    c.close()

@@ -29,7 +29,7 @@ SYMBOLS = (
     "vfsx_corpus_get_rows_f32", "vfsx_corpus_get_rows_raw", "vfsx_corpus_get_ids",
     "vfsx_corpus_fill_synthetic", "vfsx_search", "vfsx_search_device",
     "vfsx_merge_hits_device", "vfsx_merge_hits_host", "vfsx_corpus_set_profiling",
-    "vfsx_corpus_scan_time_ms",
+    "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats",
 )
 
 
@@ -97,6 +97,8 @@ def load() -> C.CDLL:
     lib.vfsx_merge_hits_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
     lib.vfsx_merge_hits_host.argtypes = [hitp, C.c_uint32, C.c_uint32, C.c_uint32, hitp]
     lib.vfsx_corpus_set_profiling.argtypes = [vp, C.c_int]
+    lib.vfsx_corpus_enable_mfma.argtypes = [vp, C.c_int]
+    lib.vfsx_corpus_mfma_stats.argtypes = [vp, u64p, u64p, C.c_int]
     lib.vfsx_corpus_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it

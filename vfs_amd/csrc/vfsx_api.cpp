@@ -141,6 +141,21 @@ struct vfsx_corpus {
     uint64_t nq_per_pass_max = 8;
     int nt_override = 2;     // 2 = auto
 
+    // many-query batches on the matrix cores (vfsx_mfma.hip): bf16 mirror + workspaces
+    bool mfma_enabled = false;
+    uint4 *d_mirror = nullptr;
+    uint64_t mirror_rows = 0; // rows the mirror currently covers (0 = stale / absent)
+    size_t mirror_bytes = 0;
+    int *d_mirror_bad = nullptr; // device flag: a row with zero / non-finite norm exists
+    bool mirror_bad = false;
+    uint32_t mfma_min_batch = 64;
+    DeviceBuf<uint8_t> q_mirror;
+    DeviceBuf<int> q_bad, q_flags;
+    DeviceBuf<float> cand;
+    DeviceBuf<uint64_t> sel;
+    std::vector<int> h_flags;
+    uint64_t mfma_queries = 0, mfma_fallbacks = 0;
+
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -309,9 +324,9 @@ void prof_collect(vfsx_corpus *c)
     c->prof_used = 0;
 }
 
-// enqueue the whole search on `s`; no host synchronisation
-void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
-                        vfsx_hit *d_hits, hipStream_t s)
+// the exact scan: enqueue the whole search on `s`; no host synchronisation
+void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                         vfsx_hit *d_hits, hipStream_t s)
 {
     if (metric < VFSX_EUCLIDEAN || metric > VFSX_SIMD_COSINE)
         fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
@@ -400,6 +415,146 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     }
 }
 
+void free_mirror(vfsx_corpus *c)
+{
+    if (c->d_mirror)
+        (void)hipFree(c->d_mirror);
+    c->d_mirror = nullptr;
+    c->mirror_rows = 0;
+    c->mirror_bytes = 0;
+}
+
+// (re)build the bf16 mirror when rows were appended since it was made
+void ensure_mirror(vfsx_corpus *c, hipStream_t s)
+{
+    if (c->mirror_rows == c->n_rows && c->d_mirror)
+        return;
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
+    if (g.mirror_bytes > c->mirror_bytes) {
+        free_mirror(c);
+        HIP_CHECK(hipMalloc((void **)&c->d_mirror, g.mirror_bytes));
+        c->mirror_bytes = g.mirror_bytes;
+    }
+    if (!c->d_mirror_bad)
+        HIP_CHECK(hipMalloc((void **)&c->d_mirror_bad, sizeof(int)));
+    HIP_CHECK(hipMemsetAsync(c->d_mirror_bad, 0, sizeof(int), s));
+    HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror, (uint32_t)c->n_rows,
+                                       c->dim, c->d_chunks, g.KS, g.n_rowtiles, c->d_mirror_bad, s));
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    c->mirror_bad = bad != 0;
+    c->mirror_rows = c->n_rows;
+}
+
+// cosine batches on the matrix cores: prefilter -> select -> exact re-score + safety check,
+// then the exact scan for every query the check could not clear (see vfsx_mfma.hip).
+// Synchronises `s` once to read the per-query flags.
+void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                        vfsx_hit *d_hits, hipStream_t s)
+{
+    use_device(c);
+    ensure_mirror(c, s);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
+    const uint32_t kp = k <= 8 ? 64u : (k <= 32 ? 128u : 256u);
+    const float eps = vfsx::mfma_epsilon(g.k_pad);
+
+    const uint32_t q_stride_pad = c->d_chunks * c->epc;
+    const bool need_pad = (q_stride_pad != c->dim);
+    const float *q_ptr = d_queries;
+    uint32_t q_stride = c->dim;
+    if (need_pad) {
+        c->q_pad.reserve((size_t)nq * q_stride_pad);
+        HIP_CHECK(vfsx::launch_query_pad(d_queries, nq, c->dim, c->q_pad.p, q_stride_pad, s));
+        q_ptr = c->q_pad.p;
+        q_stride = q_stride_pad;
+    }
+    // queries per round: candidate workspace (2 floats per list and query) capped at 1 GiB
+    const uint64_t per_q = (uint64_t)g.n_lists * 2u * sizeof(float);
+    uint32_t q_round = (uint32_t)std::max<uint64_t>(128, std::min<uint64_t>(nq, (1ull << 30) / per_q) / 128u * 128u);
+    q_round = std::min<uint32_t>(q_round, (nq + 127u) / 128u * 128u);
+    c->cand.reserve((size_t)q_round * 2u * g.n_lists);
+    c->sel.reserve((size_t)q_round * kp);
+    c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
+    c->q_bad.reserve(nq);
+    c->q_flags.reserve(nq);
+    c->h_flags.assign(nq, 0);
+
+    for (uint32_t q0 = 0; q0 < nq; q0 += q_round) {
+        const uint32_t qn = std::min(q_round, nq - q0);
+        const uint32_t qn_pad = (qn + 127u) / 128u * 128u;
+        HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * 2u, s));
+        HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
+                                               c->q_bad.p + q0, s));
+        size_t slot = 0;
+        prof_begin(c, s, slot);
+        HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g.n_rowtiles,
+                                              g.KS, qn, g.n_lists, g.strip_tiles, s));
+        prof_end(c, s, slot);
+        HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, s));
+        vfsx::MfmaRescoreArgs a{};
+        a.corpus = c->d_corpus;
+        a.row_norms = c->d_norms;
+        a.queries = q_ptr + (size_t)q0 * q_stride;
+        a.lut = c->d_lut;
+        a.sel = c->sel.p;
+        a.q_bad = c->q_bad.p + q0;
+        a.ids = c->explicit_ids ? c->d_ids : nullptr;
+        a.out = d_hits + (size_t)q0 * k;
+        a.flags = c->q_flags.p + q0;
+        a.n_rows = (uint32_t)c->n_rows;
+        a.d_chunks = c->d_chunks;
+        a.q_stride = q_stride;
+        a.k = k;
+        a.kp = kp;
+        a.eps = eps;
+        a.row_base = c->row_base;
+        a.id_base = c->id_base;
+        a.strip_tiles = g.strip_tiles;
+        HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
+    }
+    HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    c->mfma_queries += nq;
+    // exact scan for the queries the check flagged, in contiguous runs
+    for (uint32_t q = 0; q < nq;) {
+        if (!c->h_flags[q]) {
+            ++q;
+            continue;
+        }
+        uint32_t e = q;
+        while (e < nq && c->h_flags[e])
+            ++e;
+        exact_search_device(c, d_queries + (size_t)q * c->dim, e - q, k, metric, d_hits + (size_t)q * k, s);
+        c->mfma_fallbacks += e - q;
+        q = e;
+    }
+}
+
+void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                        vfsx_hit *d_hits, hipStream_t s)
+{
+    if (metric < VFSX_EUCLIDEAN || metric > VFSX_SIMD_COSINE)
+        fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
+    if (k == 0 || k > VFSX_MAX_K)
+        fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
+    if (nq == 0)
+        return;
+    if (!d_queries || !d_hits)
+        fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
+    const bool mfma_ok = c->mfma_enabled && is_cosine(metric) && nq >= c->mfma_min_batch && k <= 64 &&
+                         c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
+    if (mfma_ok) {
+        use_device(c);
+        ensure_mirror(c, s);
+        if (!c->mirror_bad) {
+            mfma_search_device(c, d_queries, nq, k, metric, d_hits, s);
+            return;
+        }
+    }
+    exact_search_device(c, d_queries, nq, k, metric, d_hits, s);
+}
+
 vfsx_corpus *checked(vfsx_corpus *c)
 {
     if (!c)
@@ -471,6 +626,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->unroll_override = (int)env_u64("VFSX_SCAN_UNROLL", 0);
         c->nt_override = (int)env_u64("VFSX_SCAN_NT", 2);
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
+        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)
@@ -507,6 +663,14 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
         if (c->stage_done[i])
             (void)hipEventDestroy(c->stage_done[i]);
     }
+    free_mirror(c);
+    if (c->d_mirror_bad)
+        (void)hipFree(c->d_mirror_bad);
+    c->q_mirror.release();
+    c->q_bad.release();
+    c->q_flags.release();
+    c->cand.release();
+    c->sel.release();
     c->lists.release();
     c->q_in.release();
     c->q_pad.release();
@@ -678,6 +842,32 @@ int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint
             });
             std::memcpy(&out[(size_t)q * k], tmp.data(), k * sizeof(vfsx_hit));
         }
+    });
+}
+
+int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
+{
+    return guarded([&] {
+        checked(c);
+        use_device(c);
+        c->mfma_enabled = enable != 0;
+        if (!enable)
+            free_mirror(c);
+        else if (c->n_rows)
+            ensure_mirror(c, c->stream);
+    });
+}
+
+int vfsx_corpus_mfma_stats(vfsx_corpus *c, uint64_t *queries, uint64_t *fallbacks, int reset)
+{
+    return guarded([&] {
+        checked(c);
+        if (queries)
+            *queries = c->mfma_queries;
+        if (fallbacks)
+            *fallbacks = c->mfma_fallbacks;
+        if (reset)
+            c->mfma_queries = c->mfma_fallbacks = 0;
     });
 }
 

@@ -73,6 +73,46 @@ hipError_t launch_get_rows(int dtype, const uint4 *corpus, uint32_t dim, uint32_
 hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
                              vfsx_hit *d_out, hipStream_t s);
 
+// ---- many-query batches on the matrix cores (vfsx_mfma.hip) ---------------------------------
+struct MfmaGeometry {
+    uint32_t k_pad;      // dim rounded up to 64
+    uint32_t KS;         // k_pad / 16 fragment k-steps
+    uint32_t n_rowtiles; // ceil(n_rows / 128)
+    uint32_t strip_tiles; // row tiles per strip (1..32)
+    uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
+    uint32_t n_lists;    // candidate lists per query = 4 * n_strips
+    size_t mirror_bytes; // bf16 mirror of the corpus
+};
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim);
+float mfma_epsilon(uint32_t k_pad);
+
+struct MfmaRescoreArgs {
+    const uint4 *corpus;
+    const float *row_norms;
+    const float *queries; // [nq][q_stride] f32 (zero padded to the chunk)
+    const float *lut;
+    const uint64_t *sel;  // [nq][kp]
+    const int *q_bad;     // [nq]
+    const uint64_t *ids;
+    vfsx_hit *out;        // [nq][k]
+    int *flags;           // [nq] 1 = not verified, re-run exactly
+    uint32_t n_rows, d_chunks, q_stride, k, kp;
+    float eps;
+    uint64_t row_base, id_base;
+    uint32_t strip_tiles;
+};
+hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
+                              uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
+                              uint32_t n_rowtiles, int *bad_flag, hipStream_t s);
+hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
+                                  int *q_bad, hipStream_t s);
+hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
+                                 uint32_t n_rowtiles, uint32_t KS, uint32_t nq, uint32_t n_lists,
+                                 uint32_t strip_tiles, hipStream_t s);
+hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
+                              hipStream_t s);
+hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);
+
 // host helpers shared with the host merge
 inline uint32_t host_dist_key(float d)
 {

@@ -15,6 +15,7 @@
 //   * one list per workgroup goes to HBM; a tiny select kernel merges them.
 #include <hip/hip_runtime.h>
 
+#include "vfsx_device.h"
 #include "vfsx_internal.h"
 
 // No FMA contraction anywhere in this file, whatever the command line says.
@@ -23,288 +24,6 @@
 namespace vfsx {
 
 namespace {
-
-// One IEEE-754 binary32 operation each, round-to-nearest-even.  NOT the HIP
-// __f*_rn intrinsics: without OCML_BASIC_ROUNDED_OPERATIONS __fsqrt_rn is the
-// *native* (1 ulp) sqrt.  sqrtf and `/` are correctly rounded because hipcc's
-// -fhip-fp32-correctly-rounded-divide-sqrt is on by default (the Makefile also
-// passes it explicitly); tests/test_gpu_parity.py checks both bit-for-bit.
-__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
-__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
-__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
-__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
-__device__ __forceinline__ float f_sqrt(float a) { return __builtin_sqrtf(a); }
-
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlock = 64 * kWavesPerBlock;
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// ---- key <-> distance ---------------------------------------------------------
-// Monotone map of an f32 to a u32 so that u32 order == the reference's
-// partial_cmp order (rank.rs:170) for non-NaN values, with -0.0 == +0.0.
-// NaN (outside the reference's defined behaviour) sorts last.
-__device__ __forceinline__ uint32_t dist_key(float d)
-{
-    uint32_t b = __float_as_uint(d);
-    if ((b & 0x7fffffffu) > 0x7f800000u)
-        return 0xffffffffu;
-    if (b == 0x80000000u)
-        b = 0u;
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-__device__ __forceinline__ float key_dist(uint32_t k)
-{
-    if (k == 0xffffffffu)
-        return __uint_as_float(0x7fc00000u);
-    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(b);
-}
-
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l)
-{
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// lane l <- lane l-1 (lane 0 keeps its own value): one DPP move per dword
-// (wave_shr:1, a full-wavefront shift on the gfx9 family) instead of ds_bpermute.
-__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v)
-{
-    constexpr int kDppWaveShr1 = 0x138;
-    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, kDppWaveShr1, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, kDppWaveShr1, 0xf, 0xf, false);
-    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
-// ---- per-wave sorted top-k of composite keys ----------------------------------
-// Composite keys are unique (they embed the row), so insertion order is irrelevant
-// and "strictly smaller than the current k-th" is the exact acceptance test: a row
-// that ties the k-th distance has a larger row index than every list entry of that
-// distance only if it was seen later -- and then it must lose (stable sort +
-// truncate, rank.rs:170-173).  The composite order encodes exactly that.
-
-// k <= 64: lane i holds the i-th smallest key; no memory traffic at all.
-struct WaveTopKReg {
-    static constexpr bool kInRegisters = true;
-    uint64_t e;
-    uint64_t tau;
-    uint32_t k;
-    __device__ __forceinline__ void init(uint32_t k_, uint64_t *)
-    {
-        k = k_;
-        e = kSentinel;
-        tau = kSentinel;
-    }
-    __device__ __forceinline__ void insert(uint64_t c)
-    {
-        const uint32_t lane = lane_id();
-        uint32_t p = (uint32_t)__popcll(__ballot(e < c));
-        uint64_t up = shfl_up1_u64(e);
-        e = lane < p ? e : (lane == p ? c : up);
-        tau = readlane64(e, k - 1);
-    }
-    __device__ __forceinline__ void offer(uint64_t comp)
-    {
-        uint64_t m = __ballot(comp < tau);
-        while (m) {
-            uint32_t l = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            uint64_t c = readlane64(comp, l);
-            if (c < tau)
-                insert(c);
-        }
-    }
-    // entry i (i < 64) for lane i
-    __device__ __forceinline__ uint64_t mine() const { return e; }
-    __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
-    {
-        if (lane_id() < k)
-            dst[lane_id() * stride] = e;
-    }
-};
-
-// any k: the list lives in LDS (one per wave), ascending, kSentinel padded.
-struct WaveTopKLds {
-    static constexpr bool kInRegisters = false;
-    uint64_t *L;
-    uint64_t tau;
-    uint32_t k;
-    __device__ __forceinline__ void init(uint32_t k_, uint64_t *lds)
-    {
-        k = k_;
-        L = lds;
-        for (uint32_t i = lane_id(); i < k; i += 64)
-            L[i] = kSentinel;
-        tau = kSentinel;
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ void insert(uint64_t c)
-    {
-        const uint32_t lane = lane_id();
-        uint32_t p = 0;
-        for (uint32_t base = 0; base < k; base += 64) {
-            uint32_t idx = base + lane;
-            uint64_t v = idx < k ? L[idx] : kSentinel;
-            p += (uint32_t)__popcll(__ballot(v < c));
-        }
-        // shift [p, k-2] up by one, top chunk first; one wave = one instruction
-        // stream, LDS executes a wave's instructions in order, the barriers only
-        // stop the compiler from moving a chunk's store above the next chunk's load.
-        for (int base = (int)(((k - 1) / 64) * 64); base >= 0; base -= 64) {
-            if ((uint32_t)base + 63u < p)
-                break;
-            uint32_t idx = (uint32_t)base + lane;
-            uint64_t v = idx < k ? L[idx] : kSentinel;
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (idx >= p && idx + 1 < k)
-                L[idx + 1] = v;
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0)
-            L[p] = c;
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        tau = L[k - 1];
-    }
-    __device__ __forceinline__ void offer(uint64_t comp)
-    {
-        uint64_t m = __ballot(comp < tau);
-        while (m) {
-            uint32_t l = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            uint64_t c = readlane64(comp, l);
-            if (c < tau)
-                insert(c);
-        }
-    }
-    __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
-    {
-        for (uint32_t i = lane_id(); i < k; i += 64)
-            dst[i * stride] = L[i];
-    }
-};
-
-// ---- distance accumulation -----------------------------------------------------
-// `q` is wave-uniform (kernel argument + uniform offsets): the compiler emits
-// s_load and feeds SGPR operands.  Strictly sequential per lane.
-// Cosine also needs ||q|| (rank.rs:296, recomputed per candidate by the reference):
-// with WITH_QQ every lane folds q_j*q_j into a second accumulator in the same j
-// order while it walks its first row-block -- the VALU has >10x headroom under the
-// HBM stream, so this costs no time and saves a kernel launch per query.
-struct Acc {
-    float a;  // sum (q-x)^2  or  sum q*x
-    float qq; // sum q*q (cosine, first row-block of the wave only)
-};
-
-template <int METRIC, bool WITH_QQ>
-__device__ __forceinline__ void acc_step(Acc &acc, float qv, float xv)
-{
-    if (METRIC == VFSX_EUCLIDEAN) { // rank.rs:284: (a - b).powi(2), a = query
-        float diff = f_sub(qv, xv);
-        acc.a = f_add(acc.a, f_mul(diff, diff));
-    } else { // rank.rs:293: a * b
-        acc.a = f_add(acc.a, f_mul(qv, xv));
-        if (WITH_QQ)
-            acc.qq = f_add(acc.qq, f_mul(qv, qv));
-    }
-}
-
-// NQ queries share one pass over the row: element x_j is loaded once and folded into
-// NQ independent accumulators.  `q` points at query 0's chunk, `qs` is the stride
-// (floats) to the next query.  NQ == 1: q is global + wave-uniform -> s_load/SGPR.
-// NQ > 1: q is the workgroup's LDS copy; every lane reads the same address (broadcast).
-template <int METRIC, bool WITH_QQ, int NQ>
-__device__ __forceinline__ void acc_chunk_f32(Acc (&acc)[NQ], const uint4 v, const float *__restrict__ q,
-                                              uint32_t qs)
-{
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const float4 qv = *(const float4 *)(q + (size_t)n * qs);
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.x, __uint_as_float(v.x));
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.y, __uint_as_float(v.y));
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.z, __uint_as_float(v.z));
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.w, __uint_as_float(v.w));
-    }
-}
-
-// i8: the byte indexes a per-bank replica of the 256-entry dequant table in LDS
-// (lut_s[u * 32 + (lane & 31)]): lane l always hits bank l & 31 -> conflict free.
-// Dequantized once per element, shared by the NQ queries.
-template <int METRIC, bool WITH_QQ, int NQ>
-__device__ __forceinline__ void acc_word_i8(Acc (&acc)[NQ], uint32_t w, const float *__restrict__ q, uint32_t qs,
-                                            const float *lut_lane)
-{
-    float xv[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-        xv[b] = lut_lane[((w >> (8 * b)) & 0xffu) * 32u]; // (q as f32) / scale, vector.rs:135-139
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const float4 qv = *(const float4 *)(q + (size_t)n * qs);
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.x, xv[0]);
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.y, xv[1]);
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.z, xv[2]);
-        acc_step<METRIC, WITH_QQ>(acc[n], qv.w, xv[3]);
-    }
-}
-
-template <int METRIC, bool WITH_QQ, int NQ>
-__device__ __forceinline__ void acc_chunk_i8(Acc (&acc)[NQ], const uint4 v, const float *__restrict__ q,
-                                             uint32_t qs, const float *lut_lane)
-{
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.x, q + 0, qs, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.y, q + 4, qs, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.z, q + 8, qs, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.w, q + 12, qs, lut_lane);
-}
-
-template <bool NT>
-__device__ __forceinline__ uint4 load_chunk(const uint4 *p)
-{
-    if (NT) {
-        // streamed once per query: nontemporal (global_load_dwordx4 ... nt)
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 t = __builtin_nontemporal_load((const u32x4 *)p);
-        return make_uint4(t.x, t.y, t.z, t.w);
-    }
-    return *p;
-}
-
-// one row-block: lane l walks row 64*blk + l through all d_chunks chunks
-template <int DTYPE, int METRIC, int UNROLL, bool NT, bool WITH_QQ, int NQ>
-__device__ __forceinline__ void scan_rowblock(Acc (&acc)[NQ], const uint4 *__restrict__ p,
-                                              const float *__restrict__ q, uint32_t qs, const float *lut_lane,
-                                              uint32_t d_chunks)
-{
-    constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
-    uint32_t c = 0;
-    for (; c + UNROLL <= d_chunks; c += UNROLL) {
-        uint4 v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            v[u] = load_chunk<NT>(p + (size_t)(c + u) * 64u);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            if (DTYPE == VFSX_I8)
-                acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs, lut_lane);
-            else
-                acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs);
-        }
-    }
-    for (; c < d_chunks; ++c) {
-        uint4 v = load_chunk<NT>(p + (size_t)c * 64u);
-        if (DTYPE == VFSX_I8)
-            acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs, lut_lane);
-        else
-            acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs);
-    }
-}
 
 // ---- the scan kernel -------------------------------------------------------------
 // grid = (n_lists, ceil(nq / NQ)); block = 256 = 4 waves.  Wave w of the launch walks

@@ -1,0 +1,543 @@
+// vfsx_mfma.hip -- many-query batches (BASELINE config C4) as a dense contraction
+// Q . X^T on the CDNA4 matrix cores, with a fused per-lane top-2 epilogue, followed by
+// an EXACT sequential-order re-score of the surviving candidates and a rigorous check
+// that no row outside them can belong to the reference's top-k.
+//
+// The reference has no multi-query API (rank.rs:90 takes one &VFSVector); the batch is
+// defined as "A3 + A4 applied independently per query" (batch note), so
+// the observable result of this path must equal the single-query scan's bit for bit.
+// Pipeline (cosine only; Euclidean batches use the exact multi-query scan):
+//
+//   mirror   X~ = bf16(x / ||x||) in MFMA fragment order          (built once per corpus)
+//   prep     Q~ = bf16(q / ||q||) in the same order               (per batch)
+//   prefilter  S~ = X~ . Q~^T on v_mfma_f32_32x32x16_bf16; each lane keeps the best two
+//              scores of its (query, row-subset) over a strip of 4096 rows, the row's
+//              position packed into the 10 low mantissa bits            -> cand[q][2][list]
+//   select   per query: the kp best approximate scores over all lists  -> sel[q][kp]
+//   rescore  per query: exact sequential f32 distance (the scan's arithmetic) of the kp
+//            rows, exact top-k by (distance, row), and the safety check:
+//              every row NOT re-scored has  s~ < c_k - eps,  c_k = 1 - (k-th exact distance)
+//            with eps bounding |s~ - cos_reference| (see mfma_epsilon()).  A query that
+//            fails it is flagged and re-run by the exact scan (host side).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "vfsx_device.h"
+#include "vfsx_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vfsx {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t kTileRows = 128;      // corpus rows per workgroup tile (M)
+constexpr uint32_t kTileQueries = 128;   // queries per workgroup tile (N)
+constexpr uint32_t kMaxStripTiles = 32;  // row tiles per strip (runtime, <= 32): up to 4096 rows share one top-2 per lane
+constexpr uint32_t kIdxBits = 10;        // 5 bits tile-in-strip, 1 bit mi, 4 bits accumulator register
+constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f)
+{
+    uint32_t u = __float_as_uint(f); // finite inputs only (non-finite rows/queries are flagged, not mirrored)
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// ---- mirror: rb64 corpus -> normalised bf16 in fragment order ----------------------------
+// unit (g, s) = 1 KiB: lane l holds row 32g + (l & 31), k = 16s + 8(l >> 5) .. +7 -- exactly
+// the A/B operand of v_mfma_f32_32x32x16_bf16, so staging is a linear copy and every
+// fragment read is a conflict-free lane-linear ds_read_b128.
+template <int DTYPE>
+__global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
+                                   const float *__restrict__ lut, uint4 *__restrict__ mirror, uint32_t n_rows,
+                                   uint32_t dim, uint32_t d_chunks, uint32_t KS, uint64_t total_units,
+                                   int *__restrict__ bad_flag)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t unit = t >> 6;
+    if (unit >= total_units)
+        return;
+    const uint32_t lane = (uint32_t)(t & 63u);
+    const uint32_t g = (uint32_t)(unit / KS), s = (uint32_t)(unit % KS);
+    const uint32_t row = g * 32u + (lane & 31u);
+    const uint32_t k0 = s * 16u + (lane >> 5) * 8u;
+    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < n_rows) {
+        const float n2 = row_norms[row];
+        const bool ok = (n2 > 0.0f) && (n2 < __uint_as_float(0x7f800000u));
+        if (!ok) {
+            if (s == 0 && (lane >> 5) == 0)
+                atomicOr(bad_flag, 1);
+        } else {
+            const uint8_t *base = (const uint8_t *)(corpus + (size_t)(row >> 6) * d_chunks * 64u + (row & 63u));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t k = k0 + j;
+                float x = 0.0f;
+                if (k < dim) {
+                    if (DTYPE == VFSX_I8)
+                        x = lut[base[(size_t)(k >> 4) * 1024u + (k & 15u)]];
+                    else
+                        x = *(const float *)(base + (size_t)(k >> 2) * 1024u + (k & 3u) * 4u);
+                }
+                h[j] = f32_to_bf16_rne(x / n2);
+            }
+        }
+    }
+    mirror[unit * 64u + lane] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16),
+                                           h[6] | (h[7] << 16));
+}
+
+// ---- query prep: one wave per query -------------------------------------------------------
+__global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
+                                       uint16_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad)
+{
+    const uint32_t q = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const float *src = q_in + (size_t)q * dim;
+    float s = 0.0f;
+    for (uint32_t j = lane; j < dim; j += 64)
+        s += src[j] * src[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_xor(s, o, 64);
+    const float n1 = __builtin_sqrtf(s);
+    const bool ok = (n1 > 0.0f) && (n1 < __uint_as_float(0x7f800000u));
+    if (lane == 0)
+        q_bad[q] = ok ? 0 : 1;
+    if (!ok)
+        return; // mirror stays zero (memset by the host)
+    for (uint32_t k = lane; k < dim; k += 64) {
+        const uint32_t unit = (q >> 5) * KS + (k >> 4);
+        const uint32_t l2 = (q & 31u) + 32u * ((k & 15u) >> 3);
+        q_mirror[((size_t)unit * 64u + l2) * 8u + (k & 7u)] = (uint16_t)f32_to_bf16_rne(src[k] / n1);
+    }
+}
+
+// ---- prefilter GEMM ---------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const uint4 *g, uint4 *lds_wave_base)
+{
+    // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
+{
+    union {
+        uint4 u;
+        bf16x8 b;
+    } c;
+    c.u = v;
+    return c.b;
+}
+
+// grid = n_strips * n_qtiles workgroups of 256 threads (4 waves as 2(M) x 2(N), 64x64 per wave).
+__global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__restrict__ A,
+                                                             const uint4 *__restrict__ B,
+                                                             float *__restrict__ cand, uint32_t n_rows,
+                                                             uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
+                                                             uint32_t nq, uint32_t n_lists, uint32_t strip_tiles)
+{
+    __shared__ __align__(16) uint4 lds[2][2][16 * 64]; // [buffer][A | B][16 units x 64 lanes] = 64 KiB
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave_m = wave >> 1, wave_n = wave & 1u;
+
+    // XCD-aware, bijective remap: workgroups that share an XCD (id % 8) take consecutive
+    // tiles, i.e. the same row strip with different query tiles -> the strip stays in that L2
+    const uint32_t total = gridDim.x;
+    const uint32_t id = blockIdx.x, xcd = id & 7u, q8 = total >> 3, r8 = total & 7u;
+    const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
+    const uint32_t strip = t / n_qtiles, qtile = t % n_qtiles;
+    const uint32_t tile0 = strip * strip_tiles;
+    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
+    const uint32_t KT = KS >> 2;
+    const uint32_t n_it = ntiles * KT;
+
+    auto stage = [&](uint32_t it, uint32_t buf) {
+        const uint32_t tile = tile0 + it / KT, kt = it % KT;
+        if (wave < 2) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t ua = wave * 8u + u, rg = ua >> 2, ks = ua & 3u;
+                glds16(A + ((size_t)(tile * 4u + rg) * KS + kt * 4u + ks) * 64u + lane, &lds[buf][0][ua * 64u]);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t ub = (wave - 2u) * 8u + u, qg = ub >> 2, ks = ub & 3u;
+                glds16(B + ((size_t)(qtile * 4u + qg) * KS + kt * 4u + ks) * 64u + lane, &lds[buf][1][ub * 64u]);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[mi][ni][r] = 0.0f;
+    const float ninf = __uint_as_float(0xff800000u);
+    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf};
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (uint32_t it = 0; it < n_it; ++it) {
+        const uint32_t buf = it & 1u;
+        if (it + 1 < n_it)
+            stage(it + 1, buf ^ 1u);
+#pragma unroll
+        for (uint32_t ks = 0; ks < 4; ++ks) {
+            const bf16x8 a0 = as_bf16x8(lds[buf][0][((wave_m * 2u + 0u) * 4u + ks) * 64u + lane]);
+            const bf16x8 a1 = as_bf16x8(lds[buf][0][((wave_m * 2u + 1u) * 4u + ks) * 64u + lane]);
+            const bf16x8 b0 = as_bf16x8(lds[buf][1][((wave_n * 2u + 0u) * 4u + ks) * 64u + lane]);
+            const bf16x8 b1 = as_bf16x8(lds[buf][1][((wave_n * 2u + 1u) * 4u + ks) * 64u + lane]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (it % KT == KT - 1u) {
+            // tile finished: fold its 64 scores per lane into the running top-2 of each query column.
+            // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+            const uint32_t ts = it / KT;
+            const uint32_t tile_row0 = (tile0 + ts) * kTileRows;
+            const bool ragged = tile_row0 + kTileRows > n_rows;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t idx = (ts << 5) | ((uint32_t)mi << 4) | (uint32_t)r;
+                        float sp = __uint_as_float((__float_as_uint(acc[mi][ni][r]) & ~kIdxMask) | idx);
+                        if (ragged) {
+                            const uint32_t row = tile_row0 + wave_m * 64u + (uint32_t)mi * 32u + ((uint32_t)r & 3u) +
+                                                 8u * ((uint32_t)r >> 2) + 4u * (lane >> 5);
+                            if (row >= n_rows)
+                                sp = ninf;
+                        }
+                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp); // second largest of the three
+                        m1[ni] = fmaxf(m1[ni], sp);
+                        acc[mi][ni][r] = 0.0f;
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const uint32_t q = qtile * kTileQueries + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
+        if (q < nq) {
+            cand[((size_t)q * 2u + 0u) * n_lists + list] = m1[ni];
+            cand[((size_t)q * 2u + 1u) * n_lists + list] = m2[ni];
+        }
+    }
+}
+
+// ---- select: kp best approximate scores of one query ------------------------------------------
+// composite = key(-score) << 32 | list ; smaller = better.  One workgroup per query.
+template <typename TopK, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__restrict__ cand,
+                                                                 uint64_t *__restrict__ sel, uint32_t n_lists,
+                                                                 uint32_t kp)
+{
+    constexpr uint32_t BLOCK = 64u * WAVES;
+    extern __shared__ __align__(16) uint64_t dyn_lds[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint32_t list_stride = kp > 64u ? kp : 64u;
+    const float *__restrict__ src = cand + (size_t)q * 2u * n_lists;
+    const float ninf = __uint_as_float(0xff800000u);
+
+    TopK top;
+    top.init(kp, dyn_lds + wave * list_stride);
+    for (uint32_t lbase = wave * 64u; lbase < n_lists; lbase += BLOCK) {
+        const uint32_t list = lbase + lane;
+        const bool in = list < n_lists;
+        const float s0 = in ? src[list] : ninf;
+        const float s1 = in ? src[(size_t)n_lists + list] : ninf;
+        const uint64_t c0 = (s0 == ninf) ? kSentinel : (((uint64_t)dist_key(-s0) << 32) | list);
+        const uint64_t c1 = (s1 == ninf) ? kSentinel : (((uint64_t)dist_key(-s1) << 32) | list);
+        top.offer(c0);
+        top.offer(c1);
+    }
+    uint64_t *mine = dyn_lds + wave * list_stride;
+    __syncthreads();
+    if (TopK::kInRegisters) {
+        mine[lane] = kSentinel;
+        top.store(mine);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        bool alive = lane >= 1 && lane < (uint32_t)WAVES;
+        const uint64_t *other = dyn_lds + (alive ? lane : 0u) * list_stride;
+        for (uint32_t j = 0; j < kp; ++j) {
+            uint64_t c = alive ? other[j] : kSentinel;
+            if (__ballot(c < top.tau) == 0)
+                break;
+            top.offer(c);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        top.store(sel + (size_t)q * kp);
+    }
+}
+
+// ---- exact re-score + safety check ----------------------------------------------------------------
+__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles)
+{
+    const uint32_t list = (uint32_t)comp;
+    score = -key_dist((uint32_t)(comp >> 32));
+    const uint32_t idx = __float_as_uint(score) & kIdxMask;
+    const uint32_t ts = idx >> 5, mi = (idx >> 4) & 1u, r = idx & 15u;
+    const uint32_t strip = list >> 2, wave_m = (list >> 1) & 1u, half = list & 1u;
+    return (strip * strip_tiles + ts) * kTileRows + wave_m * 64u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+}
+
+template <int DTYPE, typename TopK>
+__global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
+    const uint4 *__restrict__ corpus, const float *__restrict__ row_norms, const float *__restrict__ queries,
+    const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
+    const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
+    uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, float eps, uint64_t row_base, uint64_t id_base,
+    uint32_t strip_tiles)
+{
+    constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
+    extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)]
+    __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
+    __shared__ uint32_t s_list[256];
+    __shared__ float s_dk;
+    __shared__ int s_flag;
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint32_t list_stride = k > 64u ? k : 64u;
+    if (DTYPE == VFSX_I8) {
+        for (uint32_t i = threadIdx.x; i < 256u * 32u; i += kBlock)
+            lut_s[i] = lut[i >> 5];
+    }
+    if (threadIdx.x == 0)
+        s_flag = q_bad[q];
+    __syncthreads();
+    const float *lut_lane = lut_s + (lane & 31u);
+    const float *__restrict__ qv = queries + (size_t)q * q_stride;
+
+    TopK top;
+    top.init(k, dyn_lds + wave * list_stride);
+
+    const uint32_t ci = wave * 64u + lane;
+    const uint64_t comp_a = ci < kp ? sel[(size_t)q * kp + ci] : kSentinel;
+    const bool valid = comp_a != kSentinel;
+    float score = 0.0f;
+    uint32_t row = 0;
+    if (valid)
+        row = cand_row(comp_a, score, strip_tiles);
+    const bool in_range = valid && row < n_rows;
+    if (wave * 64u < kp) { // wave-uniform: this wave has candidates
+        const uint32_t r = in_range ? row : 0u;
+        const uint4 *__restrict__ p = corpus + (size_t)(r >> 6) * d_chunks * 64u + (r & 63u);
+        Acc acc[1] = {Acc{0.0f, 0.0f}};
+        for (uint32_t c = 0; c < d_chunks; ++c) {
+            const uint4 v = p[(size_t)c * 64u];
+            if (DTYPE == VFSX_I8)
+                acc_chunk_i8<VFSX_COSINE, true, 1>(acc, v, qv + c * EPC, 0, lut_lane);
+            else
+                acc_chunk_f32<VFSX_COSINE, true, 1>(acc, v, qv + c * EPC, 0);
+        }
+        uint64_t comp = kSentinel;
+        if (in_range) {
+            const float qn = f_sqrt(acc[0].qq);
+            const float den = f_mul(qn, row_norms[row]);
+            const float dist = f_sub(1.0f, f_div(acc[0].a, den)); // rank.rs:299
+            comp = ((uint64_t)dist_key(dist) << 32) | row;
+        }
+        top.offer(comp);
+    }
+
+    uint64_t *mine = dyn_lds + wave * list_stride;
+    __syncthreads();
+    if (TopK::kInRegisters) {
+        mine[lane] = kSentinel;
+        top.store(mine);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const uint64_t *other = dyn_lds + w * list_stride;
+            for (uint32_t base = 0; base < k; base += 64) {
+                uint32_t idx = base + lane;
+                uint64_t comp = idx < k ? other[idx] : kSentinel;
+                top.offer(comp);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        top.store(mine);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        for (uint32_t j = lane; j < k; j += 64) {
+            const uint64_t comp = mine[j];
+            vfsx_hit h;
+            if (comp == kSentinel) {
+                h.dist = __uint_as_float(0x7fc00000u);
+                h.flags = 0;
+                h.row = ~0ull;
+                h.id = ~0ull;
+            } else {
+                const uint32_t r = (uint32_t)comp;
+                h.dist = key_dist((uint32_t)(comp >> 32));
+                h.flags = 1;
+                h.row = row_base + r;
+                h.id = ids ? ids[r] : id_base + r;
+            }
+            out[(size_t)q * k + j] = h;
+        }
+        if (lane == 0) {
+            const uint64_t kth = mine[k - 1];
+            s_dk = kth == kSentinel ? __uint_as_float(0x7fc00000u) : key_dist((uint32_t)(kth >> 32));
+        }
+    }
+    __syncthreads();
+
+    // safety check.  A row r that was not re-scored can only belong to the exact top-k if
+    // dist_r <= D_k, i.e. cos_ref(r) >= c_k = 1 - D_k, hence (|s~ - cos_ref| <= eps) s~_r >= c_k - eps.
+    const float dk = s_dk;
+    const float thr = (1.0f - dk) - eps;
+    bool bad = !(dk == dk) || !(dk < __uint_as_float(0x7f800000u)); // fewer than k exact hits / NaN
+    const bool above = valid && score >= thr;
+    // (1) rows listed but not selected score <= the worst selected one (sel is sorted, full => index kp-1)
+    if (ci == kp - 1u && valid && above)
+        bad = true;
+    // (2) rows dropped inside a list score <= that list's 2nd entry: a list with both entries above the
+    //     margin may hide a third row that matters
+    s_list[threadIdx.x] = above ? (uint32_t)comp_a : (0xffffffffu - threadIdx.x);
+    __syncthreads();
+    if (above) {
+        const uint32_t my = (uint32_t)comp_a;
+        for (uint32_t j = 0; j < ci; ++j)
+            if (s_list[j] == my)
+                bad = true;
+    }
+    if (valid && !in_range) // cannot happen (rows >= n_rows are masked in the prefilter); be loud if it does
+        bad = true;
+    if (bad)
+        atomicOr(&s_flag, 1);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        flags[q] = s_flag;
+}
+
+} // namespace
+
+// ---- launchers ----------------------------------------------------------------------------------------
+
+hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
+                              uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
+                              uint32_t n_rowtiles, int *bad_flag, hipStream_t s)
+{
+    const uint64_t total_units = (uint64_t)n_rowtiles * 4u * KS;
+    const uint64_t threads = total_units * 64u;
+    const uint64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    if (dtype == VFSX_I8)
+        hipLaunchKernelGGL((mfma_mirror_kernel<VFSX_I8>), dim3((uint32_t)blocks), dim3(256), 0, s, corpus, row_norms,
+                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag);
+    else
+        hipLaunchKernelGGL((mfma_mirror_kernel<VFSX_F32>), dim3((uint32_t)blocks), dim3(256), 0, s, corpus, row_norms,
+                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
+                                  int *q_bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_query_prep_kernel, dim3(nq), dim3(64), 0, s, d_queries, nq, dim, (uint16_t *)q_mirror, KS,
+                       q_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
+                                 uint32_t n_rowtiles, uint32_t KS, uint32_t nq, uint32_t n_lists,
+                                 uint32_t strip_tiles, hipStream_t s)
+{
+    const uint32_t n_qtiles = (nq + kTileQueries - 1) / kTileQueries;
+    const uint32_t n_strips = (n_rowtiles + strip_tiles - 1) / strip_tiles;
+    hipLaunchKernelGGL(mfma_prefilter_kernel, dim3(n_strips * n_qtiles), dim3(256), 0, s, mirror,
+                       (const uint4 *)q_mirror, cand, n_rows, n_rowtiles, KS, n_qtiles, nq, n_lists, strip_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
+                              hipStream_t s)
+{
+    constexpr int W = 16;
+    const uint32_t list_stride = kp > 64u ? kp : 64u;
+    const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
+    if (kp <= kMaxRegisterK)
+        hipLaunchKernelGGL((mfma_select_kernel<WaveTopKReg, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
+                           kp);
+    else
+        hipLaunchKernelGGL((mfma_select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
+                           kp);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s)
+{
+    const uint32_t list_stride = a.k > 64u ? a.k : 64u;
+    const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
+    if (dtype == VFSX_I8)
+        hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_I8, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
+                           a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
+                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles);
+    else
+        hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_F32, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
+                           a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
+                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles);
+    return hipGetLastError();
+}
+
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim)
+{
+    MfmaGeometry g;
+    g.k_pad = (dim + 63u) / 64u * 64u;
+    g.KS = g.k_pad / 16u;
+    g.n_rowtiles = (n_rows + kTileRows - 1) / kTileRows;
+    // aim for >= ~4096 candidate lists per query so that two rows above the safety margin rarely share
+    // one (small corpora get short strips -- and more workgroups), capped at 32 tiles (5 index bits)
+    g.strip_tiles = std::min<uint32_t>(kMaxStripTiles, std::max<uint32_t>(1u, g.n_rowtiles / 1024u));
+    g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
+    g.n_lists = g.n_strips * 4u;
+    g.mirror_bytes = (size_t)g.n_rowtiles * kTileRows * g.k_pad * 2u;
+    return g;
+}
+
+// |s~ - cos_reference| <= eps for every (query, row) with finite, non-zero norms:
+//   2^-8 + 2^-21  two bf16 roundings (RNE, 8-bit significand: 2^-9 each) of x/||x|| and q/||q||,
+//                 each preceded by one f32 division (2^-24), cross terms included; sum |terms| <= 1;
+//   2^-13         the 10 low mantissa bits of the score replaced by the row position;
+//   (4K+32)2^-24  f32 accumulation of K exact bf16 x bf16 products inside the MFMA (any order), plus
+//                 the reference's own f32 rounding of dot, both norms, their product, the quotient
+//                 and the final subtraction (rank.rs:291-299);
+//   2^-20         slack for flushed bf16 subnormals.
+float mfma_epsilon(uint32_t k_pad)
+{
+    return 0x1p-8f + 0x1p-21f + 0x1p-13f + (4.0f * (float)k_pad + 32.0f) * 0x1p-24f + 0x1p-20f;
+}
+
+} // namespace vfsx

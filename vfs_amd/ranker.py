@@ -170,6 +170,15 @@ class Corpus:
         _lib.check(self._lib.vfsx_search_device(self._h, C.c_void_p(d_queries_ptr), nq, k, int(metric),
                                                 C.c_void_p(d_hits_ptr), C.c_void_p(stream_ptr)))
 
+    def enable_mfma(self, enabled: bool = True) -> None:
+        """Build (or drop) the bf16 mirror that lets large Cosine batches run on the matrix cores."""
+        _lib.check(self._lib.vfsx_corpus_enable_mfma(self._h, 1 if enabled else 0))
+
+    def mfma_stats(self, reset: bool = False) -> Tuple[int, int]:
+        q, f = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.vfsx_corpus_mfma_stats(self._h, C.byref(q), C.byref(f), 1 if reset else 0))
+        return q.value, f.value
+
     def set_profiling(self, enabled: bool) -> None:
         _lib.check(self._lib.vfsx_corpus_set_profiling(self._h, 1 if enabled else 0))
 
