@@ -36,7 +36,10 @@ WORKLOADS = {
     "c3": (10_000_000, 128, True, 0, "C3 10Mx128 int8 QuantizedVector Euclidean exact top-10"),
     "c1": (100_000, 128, False, 2, "C1 100kx128 f32 SimdEuclidean exact top-10"),
     "c5": (12_500_000, 768, False, 0, "C5 shard 12.5Mx768 f32 Euclidean (100Mx768 over 8 GPUs)"),
+    "c4": (10_000_000, 1024, False, 1, "C4 4096-query batch x 10Mx1024 Cosine as Q.X^T on bf16 MFMA + fused top-k, "
+                                        "exact f32 re-score"),
 }
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
 def main() -> int:
@@ -93,6 +96,13 @@ def main() -> int:
 
     dbg("process group up")
     rows, dim, quantize, metric, label = WORKLOADS[args.workload]
+    mfma = args.workload == "c4"
+    if mfma:
+        args.mode = "batch"
+        if args.queries_per_step == 16:
+            args.queries_per_step = 4096
+        if args.steps == 40:
+            args.steps, args.warmup = 5, 1
     if args.rows:
         rows = args.rows
     k = args.k
@@ -102,6 +112,8 @@ def main() -> int:
     corpus = vfs_amd.Corpus(dim, quantize=quantize, capacity_rows=rows, device=local_rank)
     corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
     corpus.set_row_base(rank * rows)
+    if mfma:
+        corpus.enable_mfma(True)
 
     dbg("corpus filled")
     n_q = (args.steps + args.warmup) * qps_step
@@ -161,6 +173,11 @@ def main() -> int:
     avg_ms = scan_ms / max(scan_launches, 1)
     algo_bytes = rows * dim * elem  # N*d*sizeof(elem) per query, ids/norms excluded
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    if mfma:  # flops = 2 * nq * N * d per batch; the dominant kernel is the prefilter GEMM
+        launches_per_batch = max(1, round(scan_launches / max(min(args.steps, 8), 1)))
+        flops = 2.0 * qps_step * rows * dim / launches_per_batch
+        tflops = flops / (avg_ms * 1e-3) / 1e12
+        mq, mf = corpus.mfma_stats()
 
     queries = args.steps * qps_step
     qps_global = queries / elapsed
@@ -189,6 +206,14 @@ def main() -> int:
                      "kernel": "scan_kernel", "avg_kernel_ms": round(avg_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches)},
     }
+    if mfma:
+        out["roofline"] = {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": "mfma_prefilter_kernel", "avg_kernel_ms": round(avg_ms, 4),
+                           "algorithmic_flops_per_launch": flops, "launches_timed": int(scan_launches)}
+        out["mfma_queries"] = int(mq)
+        out["mfma_fallback_queries"] = int(mf)
+        out["dtype"] = "bf16 MFMA prefilter + f32 exact re-score"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, rows, dim, quantize, metric, k)

@@ -35,7 +35,7 @@ bench = json.loads(bench_line)
 out = {"bench_line_under_profiler": bench, "kernels": []}
 md = [f"# rocprofv3 summary `{tag}` ({rnd})", "",
       "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline "
-      f"--workload {tag} --steps 20 --warmup 3`; PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (one run each).",
+      f"--workload {tag}` (steps/warmup as in tools_profile.sh); PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (one run each).",
       "", "| kernel | calls | avg µs | % time | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM bytes/launch (2·fetch+write) |",
       "|---|---|---|---|---|---|---|"]
 for r in rows:
@@ -51,12 +51,20 @@ for r in rows:
                            "pct": float(r["Percentage"]), "fetch_kib": f, "write_kib": w, "hbm_bytes": traffic})
     md.append(f"| `{short[:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} | "
               f"{'' if f is None else round(f,1)} | {'' if w is None else round(w,1)} | {'' if traffic is None else traffic} |")
-scan = [k for k in out["kernels"] if "scan_kernel" in k["name"]][0]
-algo = bench["roofline"]["algorithmic_bytes_per_launch"]
-md += ["", f"Dominant kernel: scan. Algorithmic bytes/launch {algo}; measured HBM bytes/launch {scan['hbm_bytes']} "
-       f"(ratio {scan['hbm_bytes']/algo:.4f}); avg duration {scan['avg_ns']/1e3:.1f} µs -> "
-       f"{algo/scan['avg_ns']:.1f} GB/s algorithmic = {algo/scan['avg_ns']/8000*100:.1f}% of the 8 TB/s HBM3E peak.",
-       "", "bench.py line from the same (profiled) run:", "", "```", bench_line.strip(), "```"]
+dom = bench["roofline"]["kernel"]
+scan = [k for k in out["kernels"] if dom in k["name"]][0]
+if bench["roofline"]["bound"] == "mfma":
+    flops = bench["roofline"]["algorithmic_flops_per_launch"]
+    md += ["", f"Dominant kernel: {dom}. Algorithmic flops/launch {flops:.4g}; avg duration {scan['avg_ns']/1e6:.2f} ms -> "
+           f"{flops/scan['avg_ns']/1e3:.1f} TFLOP/s = {flops/scan['avg_ns']/1e3/2500*100:.1f}% of the 2.5 PF dense bf16 MFMA peak; "
+           f"HBM bytes/launch {scan['hbm_bytes']} (mirror + query re-reads that miss L2/MALL).",
+           "", "bench.py line from the same (profiled) run:", "", "```", bench_line.strip(), "```"]
+else:
+    algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+    md += ["", f"Dominant kernel: scan. Algorithmic bytes/launch {algo}; measured HBM bytes/launch {scan['hbm_bytes']} "
+           f"(ratio {scan['hbm_bytes']/algo:.4f}); avg duration {scan['avg_ns']/1e3:.1f} µs -> "
+           f"{algo/scan['avg_ns']:.1f} GB/s algorithmic = {algo/scan['avg_ns']/8000*100:.1f}% of the 8 TB/s HBM3E peak.",
+           "", "bench.py line from the same (profiled) run:", "", "```", bench_line.strip(), "```"]
 out["scan_traffic_bytes_per_launch"] = scan["hbm_bytes"]
 open(f"{dst}/{tag}_summary.md", "w").write("\n".join(md) + "\n")
 json.dump(out, open(f"{dst}/{tag}_summary.json", "w"), indent=1)

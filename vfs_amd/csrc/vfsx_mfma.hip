@@ -10,9 +10,9 @@
 //
 //   mirror   X~ = bf16(x / ||x||) in MFMA fragment order          (built once per corpus)
 //   prep     Q~ = bf16(q / ||q||) in the same order               (per batch)
-//   prefilter  S~ = X~ . Q~^T on v_mfma_f32_32x32x16_bf16; each lane keeps the best two
+//   prefilter  S~ = X~ . Q~^T on v_mfma_f32_32x32x16_bf16; each lane keeps the best three
 //              scores of its (query, row-subset) over a strip of 4096 rows, the row's
-//              position packed into the 10 low mantissa bits            -> cand[q][2][list]
+//              position packed into the 10 low mantissa bits            -> cand[q][3][list]
 //   select   per query: the kp best approximate scores over all lists  -> sel[q][kp]
 //   rescore  per query: exact sequential f32 distance (the scan's arithmetic) of the kp
 //            rows, exact top-k by (distance, row), and the safety check:
@@ -38,6 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr uint32_t kTileRows = 128;      // corpus rows per workgroup tile (M)
 constexpr uint32_t kTileQueries = 128;   // queries per workgroup tile (N)
 constexpr uint32_t kMaxStripTiles = 32;  // row tiles per strip (runtime, <= 32): up to 4096 rows share one top-2 per lane
+constexpr uint32_t kListDepth = 3;       // scores kept per candidate list
 constexpr uint32_t kIdxBits = 10;        // 5 bits tile-in-strip, 1 bit mi, 4 bits accumulator register
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
 
@@ -149,12 +150,24 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t wave_m = wave >> 1, wave_n = wave & 1u;
 
-    // XCD-aware, bijective remap: workgroups that share an XCD (id % 8) take consecutive
-    // tiles, i.e. the same row strip with different query tiles -> the strip stays in that L2
+    // XCD-aware mapping (speed only).  Workgroups with equal id % 8 share an XCD and its 4 MiB L2.
+    // Give each XCD a fixed slice of the query tiles (its share of Q~ then stays L2-resident) and let
+    // it walk the row strips in order; all XCDs walk the strips at the same pace, so a strip fetched
+    // by one XCD is served to the others from the Infinity Cache.  Needs n_qtiles % 8 == 0;
+    // otherwise fall back to consecutive tiles per XCD (bijective remap).
     const uint32_t total = gridDim.x;
-    const uint32_t id = blockIdx.x, xcd = id & 7u, q8 = total >> 3, r8 = total & 7u;
-    const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
-    const uint32_t strip = t / n_qtiles, qtile = t % n_qtiles;
+    const uint32_t id = blockIdx.x, xcd = id & 7u;
+    uint32_t strip, qtile;
+    if ((n_qtiles & 7u) == 0u) {
+        const uint32_t qpx = n_qtiles >> 3, within = id >> 3;
+        strip = within / qpx;
+        qtile = xcd * qpx + within % qpx;
+    } else {
+        const uint32_t q8 = total >> 3, r8 = total & 7u;
+        const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
+        strip = t / n_qtiles;
+        qtile = t % n_qtiles;
+    }
     const uint32_t tile0 = strip * strip_tiles;
     const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
     const uint32_t KT = KS >> 2;
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
             for (int r = 0; r < 16; ++r)
                 acc[mi][ni][r] = 0.0f;
     const float ninf = __uint_as_float(0xff800000u);
-    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf};
+    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf}; // running top-3 per query column
 
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -226,8 +239,12 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
                             if (row >= n_rows)
                                 sp = ninf;
                         }
-                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp); // second largest of the three
+                        // insert sp into the sorted triple (m1 >= m2 >= m3): 5 VALU ops
+                        const float lo1 = fminf(m1[ni], sp);
                         m1[ni] = fmaxf(m1[ni], sp);
+                        const float lo2 = fminf(m2[ni], lo1);
+                        m2[ni] = fmaxf(m2[ni], lo1);
+                        m3[ni] = fmaxf(m3[ni], lo2);
                         acc[mi][ni][r] = 0.0f;
                     }
         }
@@ -240,8 +257,9 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
     for (int ni = 0; ni < 2; ++ni) {
         const uint32_t q = qtile * kTileQueries + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
         if (q < nq) {
-            cand[((size_t)q * 2u + 0u) * n_lists + list] = m1[ni];
-            cand[((size_t)q * 2u + 1u) * n_lists + list] = m2[ni];
+            cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
+            cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
+            cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
         }
     }
 }
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x;
     const uint32_t list_stride = kp > 64u ? kp : 64u;
-    const float *__restrict__ src = cand + (size_t)q * 2u * n_lists;
+    const float *__restrict__ src = cand + (size_t)q * kListDepth * n_lists;
     const float ninf = __uint_as_float(0xff800000u);
 
     TopK top;
@@ -267,12 +285,13 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
     for (uint32_t lbase = wave * 64u; lbase < n_lists; lbase += BLOCK) {
         const uint32_t list = lbase + lane;
         const bool in = list < n_lists;
-        const float s0 = in ? src[list] : ninf;
-        const float s1 = in ? src[(size_t)n_lists + list] : ninf;
-        const uint64_t c0 = (s0 == ninf) ? kSentinel : (((uint64_t)dist_key(-s0) << 32) | list);
-        const uint64_t c1 = (s1 == ninf) ? kSentinel : (((uint64_t)dist_key(-s1) << 32) | list);
-        top.offer(c0);
-        top.offer(c1);
+        float sc[kListDepth];
+#pragma unroll
+        for (uint32_t j = 0; j < kListDepth; ++j)
+            sc[j] = in ? src[(size_t)j * n_lists + list] : ninf;
+#pragma unroll
+        for (uint32_t j = 0; j < kListDepth; ++j)
+            top.offer((sc[j] == ninf) ? kSentinel : (((uint64_t)dist_key(-sc[j]) << 32) | list));
     }
     uint64_t *mine = dyn_lds + wave * list_stride;
     __syncthreads();
@@ -422,15 +441,17 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     // (1) rows listed but not selected score <= the worst selected one (sel is sorted, full => index kp-1)
     if (ci == kp - 1u && valid && above)
         bad = true;
-    // (2) rows dropped inside a list score <= that list's 2nd entry: a list with both entries above the
-    //     margin may hide a third row that matters
+    // (2) rows dropped inside a list score <= that list's last (3rd) entry: a list with all three
+    //     entries above the margin may hide a fourth row that matters
     s_list[threadIdx.x] = above ? (uint32_t)comp_a : (0xffffffffu - threadIdx.x);
     __syncthreads();
     if (above) {
         const uint32_t my = (uint32_t)comp_a;
+        uint32_t same = 0;
         for (uint32_t j = 0; j < ci; ++j)
-            if (s_list[j] == my)
-                bad = true;
+            same += (s_list[j] == my) ? 1u : 0u;
+        if (same + 1u >= kListDepth)
+            bad = true;
     }
     if (valid && !in_range) // cannot happen (rows >= n_rows are masked in the prefilter); be loud if it does
         bad = true;
