@@ -161,6 +161,44 @@ int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64
 int vfsx_corpus_fill_synthetic(vfsx_corpus *c, uint64_t seed, uint64_t row0, uint64_t n,
                                uint64_t id0);
 
+/* ---- ingest from an existing VFS data directory ------------ */
+
+/* What a log file holds (first record's shape; the reference never mixes shapes in a store). */
+typedef struct vfsx_log_info {
+    uint64_t records;   /* well-formed records found */
+    uint32_t dim;       /* Vec length of the first record */
+    int dtype;          /* VFSX_F32 (Dense) or VFSX_I8 (Quantized) */
+    float scale;        /* scale_factor of the first record (Quantized only) */
+    uint64_t first_id, last_id;
+    uint64_t file_bytes;
+} vfsx_log_info;
+
+/*
+ * Parses the reference's append-only log `data/vectors.dat`
+ * (writer save_vector serializer.rs:25-71, reader load_vectors serializer.rs:77-153):
+ * records of  DE AD BE EF | u64-LE length | bincode(VFSVector).  The whole file is walked
+ * (not the reference's 1 KiB window, which loses every record larger than that):
+ * non-marker bytes are skipped one at a time and an incomplete trailing record ends the walk,
+ * as in the reference; a payload that does not decode is VFSX_ERR_SERIALIZATION.
+ */
+int vfsx_log_inspect(const char *path, vfsx_log_info *info);
+
+/*
+ * Appends every record of the log to the corpus in file order (= scan order), keeping the
+ * records' ids and their VectorMetadata (vector.rs:11-17) host-side.  A Quantized record
+ * loaded into a VFSX_F32 corpus is stored dequantized (as_f32_vec, vector.rs:284-288); a
+ * Dense record cannot enter a VFSX_I8 corpus (VFSVector::dequantize fails, vector.rs:194-198).
+ */
+int vfsx_corpus_load_log(vfsx_corpus *c, const char *path, uint64_t *n_loaded);
+
+/*
+ * VectorMetadata of a LOCAL row as JSON: {"name":"..","tags":[..],"created_at":".."}
+ * (empty strings for rows appended without metadata).  Writes at most cap-1 bytes + NUL;
+ * *needed receives the size required.  Feeds the /search hydration (tcp.rs:408-427).
+ */
+int vfsx_corpus_get_metadata_json(vfsx_corpus *c, uint64_t row, char *buf, uint64_t cap,
+                                  uint64_t *needed);
+
 /* ---- search (replaces Ranker::search / exact_search, rank.rs:90-186) --------- */
 
 /*

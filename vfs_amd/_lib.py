@@ -30,12 +30,19 @@ SYMBOLS = (
     "vfsx_corpus_fill_synthetic", "vfsx_search", "vfsx_search_device",
     "vfsx_merge_hits_device", "vfsx_merge_hits_host", "vfsx_corpus_set_profiling",
     "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats",
+    "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_get_metadata_json",
 )
 
 
 class Hit(C.Structure):
     """vfsx_hit (24 bytes)."""
     _fields_ = [("dist", C.c_float), ("flags", C.c_uint32), ("row", C.c_uint64), ("id", C.c_uint64)]
+
+
+class LogInfo(C.Structure):
+    """vfsx_log_info."""
+    _fields_ = [("records", C.c_uint64), ("dim", C.c_uint32), ("dtype", C.c_int), ("scale", C.c_float),
+                ("first_id", C.c_uint64), ("last_id", C.c_uint64), ("file_bytes", C.c_uint64)]
 
 
 class VfsxError(RuntimeError):
@@ -97,6 +104,9 @@ def load() -> C.CDLL:
     lib.vfsx_merge_hits_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
     lib.vfsx_merge_hits_host.argtypes = [hitp, C.c_uint32, C.c_uint32, C.c_uint32, hitp]
     lib.vfsx_corpus_set_profiling.argtypes = [vp, C.c_int]
+    lib.vfsx_log_inspect.argtypes = [C.c_char_p, C.POINTER(LogInfo)]
+    lib.vfsx_corpus_load_log.argtypes = [vp, C.c_char_p, u64p]
+    lib.vfsx_corpus_get_metadata_json.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, u64p]
     lib.vfsx_corpus_enable_mfma.argtypes = [vp, C.c_int]
     lib.vfsx_corpus_mfma_stats.argtypes = [vp, u64p, u64p, C.c_int]
     lib.vfsx_corpus_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]

@@ -12,6 +12,11 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "vfsx_internal.h"
 
 namespace {
@@ -140,6 +145,14 @@ struct vfsx_corpus {
     int unroll_override = 0; // 0 = auto
     uint64_t nq_per_pass_max = 8;
     int nt_override = 2;     // 2 = auto
+
+    // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
+    struct RowMeta {
+        std::string name;
+        std::vector<std::string> tags;
+        std::string created_at;
+    };
+    std::vector<RowMeta> meta; // empty, or one entry per row
 
     // many-query batches on the matrix cores (vfsx_mfma.hip): bf16 mirror + workspaces
     bool mfma_enabled = false;
@@ -899,6 +912,269 @@ int vfsx_corpus_scan_time_ms(vfsx_corpus *c, double *total_ms, uint64_t *launche
         if (reset) {
             c->prof_ms = 0.0;
             c->prof_launches = 0;
+        }
+    });
+}
+
+} // extern "C"
+
+// ---- F1: ingest from the reference's on-disk log (serializer.rs:25-153) ---------------------
+// record = DE AD BE EF | u64-LE payload length | bincode 1.3 (fixint, little endian) of VFSVector:
+//   u32 variant (0 Dense, 1 Quantized) | u64 id | u64 n | n x f32 or n x i8 | [f32 scale_factor] |
+//   String name | Vec<String> tags | String created_at (RFC 3339)      (String = u64 length + bytes)
+namespace {
+
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    explicit MappedFile(const char *path)
+    {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0)
+            fail(VFSX_ERR_IO, std::string("cannot open ") + path + ": " + std::strerror(errno));
+        struct stat st;
+        if (fstat(fd, &st) != 0)
+            fail(VFSX_ERR_IO, std::string("cannot stat ") + path);
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED)
+                fail(VFSX_ERR_IO, std::string("cannot map ") + path);
+            p = (const uint8_t *)m;
+        }
+    }
+    ~MappedFile()
+    {
+        if (p)
+            munmap((void *)p, n);
+        if (fd >= 0)
+            ::close(fd);
+    }
+};
+
+struct LogRecord {
+    uint32_t variant = 0;
+    uint64_t id = 0;
+    uint64_t n = 0;
+    const uint8_t *values = nullptr; // n f32 (Dense) or n i8 (Quantized), unaligned
+    float scale = 0.f;
+    vfsx_corpus::RowMeta meta;
+};
+
+struct Cursor {
+    const uint8_t *p;
+    size_t left;
+    template <typename T>
+    T get()
+    {
+        if (left < sizeof(T))
+            fail(VFSX_ERR_SERIALIZATION, "record payload truncated");
+        T v;
+        std::memcpy(&v, p, sizeof(T));
+        p += sizeof(T);
+        left -= sizeof(T);
+        return v;
+    }
+    const uint8_t *bytes(uint64_t n)
+    {
+        if (left < n)
+            fail(VFSX_ERR_SERIALIZATION, "record payload truncated");
+        const uint8_t *r = p;
+        p += n;
+        left -= (size_t)n;
+        return r;
+    }
+    std::string str()
+    {
+        uint64_t n = get<uint64_t>();
+        const uint8_t *b = bytes(n);
+        return std::string((const char *)b, (size_t)n);
+    }
+};
+
+void decode_record(const uint8_t *payload, size_t len, LogRecord &r)
+{
+    Cursor c{payload, len};
+    r.variant = c.get<uint32_t>();
+    if (r.variant > 1)
+        fail(VFSX_ERR_SERIALIZATION, "unknown VFSVector variant " + std::to_string(r.variant));
+    r.id = c.get<uint64_t>();
+    r.n = c.get<uint64_t>();
+    if (r.n > len)
+        fail(VFSX_ERR_SERIALIZATION, "vector length exceeds the record");
+    r.values = c.bytes(r.n * (r.variant == 0 ? 4u : 1u));
+    r.scale = r.variant == 1 ? c.get<float>() : 0.f;
+    r.meta.name = c.str();
+    uint64_t nt = c.get<uint64_t>();
+    if (nt > len)
+        fail(VFSX_ERR_SERIALIZATION, "tag count exceeds the record");
+    r.meta.tags.clear();
+    for (uint64_t i = 0; i < nt; ++i)
+        r.meta.tags.push_back(c.str());
+    r.meta.created_at = c.str();
+}
+
+// Walks the file the way load_vectors does (serializer.rs:101-150), minus its 1 KiB window:
+// a marker starts a record, any other byte is skipped, an incomplete trailing record ends the scan.
+template <typename F>
+uint64_t walk_log(const MappedFile &f, F &&on_record)
+{
+    static const uint8_t marker[4] = {0xDE, 0xAD, 0xBE, 0xEF}; // serializer.rs:13
+    size_t cur = 0;
+    uint64_t count = 0;
+    LogRecord r;
+    while (cur + 4 <= f.n) {
+        if (std::memcmp(f.p + cur, marker, 4) != 0) {
+            ++cur; // serializer.rs:148
+            continue;
+        }
+        if (cur + 12 > f.n)
+            break; // serializer.rs:142-146
+        uint64_t len;
+        std::memcpy(&len, f.p + cur + 4, 8);
+        if (len > f.n - (cur + 12))
+            break; // serializer.rs:137-141
+        decode_record(f.p + cur + 12, (size_t)len, r);
+        on_record(r);
+        cur += 12 + (size_t)len;
+        ++count;
+    }
+    return count;
+}
+
+void json_escape(std::string &out, const std::string &s)
+{
+    out += '"';
+    for (unsigned char ch : s) {
+        switch (ch) {
+        case '"': out += "\\\""; break;
+        case '\\': out += "\\\\"; break;
+        case '\n': out += "\\n"; break;
+        case '\r': out += "\\r"; break;
+        case '\t': out += "\\t"; break;
+        default:
+            if (ch < 0x20) {
+                char b[8];
+                std::snprintf(b, sizeof b, "\\u%04x", ch);
+                out += b;
+            } else {
+                out += (char)ch;
+            }
+        }
+    }
+    out += '"';
+}
+
+} // namespace
+
+extern "C" {
+
+int vfsx_log_inspect(const char *path, vfsx_log_info *info)
+{
+    return guarded([&] {
+        if (!path || !info)
+            fail(VFSX_ERR_INVALID_VECTOR, "null argument");
+        MappedFile f(path);
+        vfsx_log_info out{};
+        bool first = true;
+        out.records = walk_log(f, [&](const LogRecord &r) {
+            if (first) {
+                out.dim = (uint32_t)r.n;
+                out.dtype = r.variant == 1 ? VFSX_I8 : VFSX_F32;
+                out.scale = r.scale;
+                out.first_id = r.id;
+                first = false;
+            }
+            out.last_id = r.id;
+        });
+        out.file_bytes = f.n;
+        *info = out;
+    });
+}
+
+int vfsx_corpus_load_log(vfsx_corpus *c, const char *path, uint64_t *n_loaded)
+{
+    return guarded([&] {
+        checked(c);
+        if (!path)
+            fail(VFSX_ERR_INVALID_VECTOR, "null path");
+        MappedFile f(path);
+        const size_t elem = c->dtype == VFSX_I8 ? 1 : 4;
+        const uint64_t batch_rows = std::max<uint64_t>(1, (8u << 20) / ((uint64_t)c->dim * elem));
+        std::vector<uint8_t> rows;
+        std::vector<uint64_t> ids;
+        std::vector<vfsx_corpus::RowMeta> metas;
+        rows.reserve((size_t)batch_rows * c->dim * elem);
+        uint64_t total = 0;
+        auto flush = [&] {
+            if (ids.empty())
+                return;
+            if (c->meta.size() < c->n_rows)
+                c->meta.resize(c->n_rows); // rows appended earlier without metadata
+            append_impl(c, rows.data(), ids.data(), ids.size(), c->dtype == VFSX_I8 ? 1 : 0);
+            for (auto &m : metas)
+                c->meta.push_back(std::move(m));
+            total += ids.size();
+            rows.clear();
+            ids.clear();
+            metas.clear();
+        };
+        walk_log(f, [&](const LogRecord &r) {
+            if (r.n != c->dim) // tcp.rs:307-312
+                fail(VFSX_ERR_INVALID_VECTOR, "Vector dimension mismatch. Expected " + std::to_string(c->dim) +
+                                                  ", got " + std::to_string(r.n));
+            const size_t off = rows.size();
+            rows.resize(off + (size_t)c->dim * elem);
+            if (c->dtype == VFSX_I8) {
+                if (r.variant != 1) // VFSVector::dequantize on Dense (vector.rs:196-198) -> load_batch fails
+                    fail(VFSX_ERR_INVALID_VECTOR, "No se puede descuantizar un vector que ya está descuantizado");
+                if (r.scale != c->scale)
+                    fail(VFSX_ERR_INVALID_VECTOR, "record scale_factor differs from the corpus scale");
+                std::memcpy(rows.data() + off, r.values, c->dim);
+            } else if (r.variant == 0) {
+                std::memcpy(rows.data() + off, r.values, (size_t)c->dim * 4);
+            } else { // Quantized record into a dense corpus: as_f32_vec (vector.rs:284-288)
+                float *dst = (float *)(rows.data() + off);
+                for (uint32_t j = 0; j < c->dim; ++j)
+                    dst[j] = (float)(int8_t)r.values[j] / r.scale;
+            }
+            ids.push_back(r.id);
+            metas.push_back(r.meta);
+            if (ids.size() >= batch_rows)
+                flush();
+        });
+        flush();
+        if (n_loaded)
+            *n_loaded = total;
+    });
+}
+
+int vfsx_corpus_get_metadata_json(vfsx_corpus *c, uint64_t row, char *buf, uint64_t cap, uint64_t *needed)
+{
+    return guarded([&] {
+        checked(c);
+        if (row >= c->n_rows)
+            fail(VFSX_ERR_INVALID_VECTOR, "row index out of range");
+        std::string s = "{\"name\":";
+        static const vfsx_corpus::RowMeta empty;
+        const vfsx_corpus::RowMeta &m = row < c->meta.size() ? c->meta[row] : empty;
+        json_escape(s, m.name);
+        s += ",\"tags\":[";
+        for (size_t i = 0; i < m.tags.size(); ++i) {
+            if (i)
+                s += ',';
+            json_escape(s, m.tags[i]);
+        }
+        s += "],\"created_at\":";
+        json_escape(s, m.created_at);
+        s += "}";
+        if (needed)
+            *needed = s.size() + 1;
+        if (buf && cap) {
+            const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+            std::memcpy(buf, s.data(), n);
+            buf[n] = 0;
         }
     });
 }

@@ -116,6 +116,24 @@ class Corpus:
         else:
             _lib.check(self._lib.vfsx_corpus_append(self._h, rows.ctypes.data_as(C.c_void_p), idp, rows.shape[0]))
 
+    def load_log(self, path: str) -> int:
+        """Append every record of a VFS `data/vectors.dat` log (serializer.rs:25-153), keeping ids
+        and metadata.  Returns the number of records loaded."""
+        n = C.c_uint64(0)
+        _lib.check(self._lib.vfsx_corpus_load_log(self._h, str(path).encode(), C.byref(n)))
+        return int(n.value)
+
+    def get_metadata(self, row: int) -> dict:
+        """VectorMetadata (vector.rs:11-17) of a local row: {name, tags, created_at}."""
+        import json
+        need = C.c_uint64(0)
+        buf = C.create_string_buffer(512)
+        _lib.check(self._lib.vfsx_corpus_get_metadata_json(self._h, int(row), buf, len(buf), C.byref(need)))
+        if need.value > len(buf):
+            buf = C.create_string_buffer(int(need.value))
+            _lib.check(self._lib.vfsx_corpus_get_metadata_json(self._h, int(row), buf, len(buf), C.byref(need)))
+        return json.loads(buf.value.decode("utf-8"))
+
     def fill_synthetic(self, seed: int, n: int, row0: int = 0, id0: int = 1) -> None:
         _lib.check(self._lib.vfsx_corpus_fill_synthetic(self._h, seed, row0, n, id0))
 
