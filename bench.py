@@ -54,6 +54,8 @@ def main() -> int:
                     help="single: one scan launch per query (the headline); batch: one call per step, "
                          "queries share corpus passes (8 per pass)")
     ap.add_argument("--rows", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--dim", type=int, default=0, help="override the dimension (experiments only)")
+    ap.add_argument("--metric", type=int, default=-1, help="override the metric 0..3 (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     ap.add_argument("--cpu-sample-queries", type=int, default=48)
@@ -105,6 +107,10 @@ def main() -> int:
             args.steps, args.warmup = 5, 1
     if args.rows:
         rows = args.rows
+    if args.dim:
+        dim, label = args.dim, label + f" [dim overridden to {args.dim}]"
+    if args.metric >= 0:
+        metric, label = args.metric, label + f" [metric overridden to {args.metric}]"
     k = args.k
     qps_step = args.queries_per_step
     elem = 1 if quantize else 4

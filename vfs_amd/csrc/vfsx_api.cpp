@@ -145,6 +145,7 @@ struct vfsx_corpus {
     int unroll_override = 0; // 0 = auto
     uint64_t nq_per_pass_max = 8;
     int nt_override = 2;     // 2 = auto
+    int pipe_override = 2;   // 2 = auto
 
     // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
     struct RowMeta {
@@ -372,7 +373,8 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
     int unroll = c->unroll_override;
     if (unroll != 4 && unroll != 8 && unroll != 16)
         unroll = c->dtype == VFSX_I8 ? 4 : (c->d_chunks >= 64 ? 16 : 8);
-    const int scan_variant = unroll * 2 + nt;
+    const int pipe = (int)c->pipe_override == 2 ? 0 : (c->pipe_override ? 1 : 0);
+    const int scan_variant = unroll * 2 + nt + ((pipe && unroll <= 8) ? 64 : 0);
     // queries per corpus pass: as many as the batch offers (max 8), while the workgroup's
     // LDS (lists + staged queries [+ 32 KiB LUT for int8]) stays within 64 KiB
     int nq_per_pass = 1;
@@ -643,6 +645,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->unroll_override = (int)env_u64("VFSX_SCAN_UNROLL", 0);
         c->nt_override = (int)env_u64("VFSX_SCAN_NT", 2);
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
+        c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));

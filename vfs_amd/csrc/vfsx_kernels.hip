@@ -29,7 +29,7 @@ namespace {
 // grid = (n_lists, ceil(nq / NQ)); block = 256 = 4 waves.  Wave w of the launch walks
 // row-blocks w, w + W, w + 2W, ... in ascending order, NQ queries at a time.
 // dynamic LDS: [4 waves][NQ][max(k,64)] u64 lists, then (NQ > 1) [NQ][q_stride] f32 queries.
-template <int DTYPE, int METRIC, typename TopK, int UNROLL, bool NT, int NQ>
+template <int DTYPE, int METRIC, typename TopK, int UNROLL, bool NT, int NQ, bool PIPE>
 __global__ __launch_bounds__(kBlock) void scan_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
     const float *__restrict__ queries, const float *__restrict__ lut, uint64_t *__restrict__ lists,
@@ -81,20 +81,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     for (int n = 0; n < NQ; ++n)
         qn[n] = 0.0f;
 
-    for (uint32_t blk = wave_global; blk < n_rowblocks; blk += n_waves) {
-        const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
-        Acc acc[NQ];
-#pragma unroll
-        for (int n = 0; n < NQ; ++n)
-            acc[n] = Acc{0.0f, 0.0f};
-        if (METRIC == VFSX_COSINE && blk == wave_global) {
-            scan_rowblock<DTYPE, METRIC, UNROLL, NT, true, NQ>(acc, p, q, qs, lut_lane, d_chunks);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n)
-                qn[n] = f_sqrt(acc[n].qq); // rank.rs:296
-        } else {
-            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false, NQ>(acc, p, q, qs, lut_lane, d_chunks);
-        }
+    // distance of row (64 blk + lane) from its finished accumulators, offered to the wave's lists
+    auto finish_rowblock = [&](uint32_t blk, Acc(&acc)[NQ]) {
         const uint32_t row = blk * 64u + lane;
         float rn = 0.0f;
         if (METRIC == VFSX_COSINE && row < n_rows)
@@ -113,6 +101,77 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                 comp = ((uint64_t)dist_key(dist) << 32) | row;
             }
             top[n].offer(comp);
+        }
+    };
+
+    uint32_t blk = wave_global;
+    if (METRIC == VFSX_COSINE && blk < n_rowblocks) {
+        // first row-block of the wave: also folds sum q_j^2 (see Acc)
+        const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
+        Acc acc[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+            acc[n] = Acc{0.0f, 0.0f};
+        scan_rowblock<DTYPE, METRIC, UNROLL, NT, true, NQ>(acc, p, q, qs, lut_lane, d_chunks);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+            qn[n] = f_sqrt(acc[n].qq); // rank.rs:296
+        finish_rowblock(blk, acc);
+        blk += n_waves;
+    }
+    if (PIPE && d_chunks % UNROLL == 0) {
+        // software pipeline over the flat sequence of (row-block, chunk group): the next group's
+        // UNROLL loads (possibly the next row-block's first group) are in flight while the current
+        // group is accumulated, so a wave never sits with an empty memory queue.
+        constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
+        const uint32_t groups = d_chunks / UNROLL;
+        uint4 cur[UNROLL], nxt[UNROLL];
+        if (blk < n_rowblocks) {
+            const uint4 *__restrict__ p0 = corpus + (size_t)blk * d_chunks * 64u + lane;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                cur[u] = load_chunk<NT>(p0 + (size_t)u * 64u);
+        }
+        for (; blk < n_rowblocks; blk += n_waves) {
+            const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
+            const uint32_t nblk = blk + n_waves;
+            Acc acc[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+                acc[n] = Acc{0.0f, 0.0f};
+            for (uint32_t g = 0; g < groups; ++g) {
+                if (g + 1 < groups) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u)
+                        nxt[u] = load_chunk<NT>(p + (size_t)((g + 1) * UNROLL + u) * 64u);
+                } else if (nblk < n_rowblocks) {
+                    const uint4 *__restrict__ pn = corpus + (size_t)nblk * d_chunks * 64u + lane;
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u)
+                        nxt[u] = load_chunk<NT>(pn + (size_t)u * 64u);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (DTYPE == VFSX_I8)
+                        acc_chunk_i8<METRIC, false, NQ>(acc, cur[u], q + (g * UNROLL + u) * EPC, qs, lut_lane);
+                    else
+                        acc_chunk_f32<METRIC, false, NQ>(acc, cur[u], q + (g * UNROLL + u) * EPC, qs);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    cur[u] = nxt[u];
+            }
+            finish_rowblock(blk, acc);
+        }
+    } else {
+        for (; blk < n_rowblocks; blk += n_waves) {
+            const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
+            Acc acc[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+                acc[n] = Acc{0.0f, 0.0f};
+            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false, NQ>(acc, p, q, qs, lut_lane, d_chunks);
+            finish_rowblock(blk, acc);
         }
     }
 
@@ -452,17 +511,17 @@ __global__ __launch_bounds__(kBlock) void merge_hits_kernel(const vfsx_hit *__re
 
 size_t scan_lds_bytes(uint32_t k, int nq_per_pass, uint32_t q_stride);
 
-template <int DTYPE, int METRIC, int UNROLL, bool NT, int NQ>
+template <int DTYPE, int METRIC, int UNROLL, bool NT, int NQ, bool PIPE = false>
 static hipError_t launch_scan_v(const ScanArgs &a, uint32_t nq, uint32_t grid_x, hipStream_t s)
 {
     dim3 grid(grid_x, (nq + NQ - 1) / NQ), block(kBlock);
     const size_t lds = scan_lds_bytes(a.k, NQ, a.q_stride);
     if (a.k <= kMaxRegisterK) {
-        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT, NQ>), grid, block, lds, s, a.corpus,
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
                            a.q_stride, a.k, a.n_lists, nq);
     } else {
-        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT, NQ>), grid, block, lds, s, a.corpus,
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
                            a.q_stride, a.k, a.n_lists, nq);
     }
@@ -484,8 +543,12 @@ static hipError_t launch_scan_t(const ScanArgs &a, uint32_t nq, uint32_t grid_x,
     if (nq_per_pass == 2)
         return nt ? launch_scan_v<DTYPE, METRIC, 4, true, 2>(a, nq, grid_x, s)
                   : launch_scan_v<DTYPE, METRIC, 4, false, 2>(a, nq, grid_x, s);
-    // single query: variant = unroll * 2 + nt  (tuning knob; the default is chosen in vfsx_api.cpp)
+    // single query: variant = unroll * 2 + nt (+ 64 = software-pipelined); the default is chosen in vfsx_api.cpp
     switch (variant) {
+    case 64 + 4 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 4, false, 1, true>(a, nq, grid_x, s);
+    case 64 + 4 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 4, true, 1, true>(a, nq, grid_x, s);
+    case 64 + 8 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 8, false, 1, true>(a, nq, grid_x, s);
+    case 64 + 8 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 8, true, 1, true>(a, nq, grid_x, s);
     case 4 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 4, false, 1>(a, nq, grid_x, s);
     case 8 * 2 + 1: return launch_scan_v<DTYPE, METRIC, 8, true, 1>(a, nq, grid_x, s);
     case 8 * 2 + 0: return launch_scan_v<DTYPE, METRIC, 8, false, 1>(a, nq, grid_x, s);
