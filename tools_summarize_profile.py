@@ -16,13 +16,17 @@ rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = f"gpurun_out/prof_{tag}"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 shutil.copy(stats, f"{dst}/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 
 
 def pmc(kind):
-    f = glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv")[0]
+    f = newest(f"{src}/pmc_{kind}/*/*_counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))

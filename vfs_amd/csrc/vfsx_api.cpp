@@ -163,6 +163,7 @@ struct vfsx_corpus {
     int *d_mirror_bad = nullptr; // device flag: a row with zero / non-finite norm exists
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 64;
+    uint32_t mfma_wm = 4; // prefilter tile: 256 rows x 128 queries, 3-stage ring (2 = 128 x 128, 2 stages)
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
     DeviceBuf<float> cand;
@@ -444,7 +445,7 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
 {
     if (c->mirror_rows == c->n_rows && c->d_mirror)
         return;
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_wm);
     if (g.mirror_bytes > c->mirror_bytes) {
         free_mirror(c);
         HIP_CHECK(hipMalloc((void **)&c->d_mirror, g.mirror_bytes));
@@ -454,7 +455,8 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
         HIP_CHECK(hipMalloc((void **)&c->d_mirror_bad, sizeof(int)));
     HIP_CHECK(hipMemsetAsync(c->d_mirror_bad, 0, sizeof(int), s));
     HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror, (uint32_t)c->n_rows,
-                                       c->dim, c->d_chunks, g.KS, g.n_rowtiles, c->d_mirror_bad, s));
+                                       c->dim, c->d_chunks, g.KS, (uint32_t)(g.mirror_bytes / ((size_t)g.k_pad * 2u * 32u)),
+                                       c->d_mirror_bad, s));
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_bad, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -470,7 +472,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 {
     use_device(c);
     ensure_mirror(c, s);
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_wm);
     const uint32_t kp = k <= 8 ? 64u : (k <= 32 ? 128u : 256u);
     const float eps = vfsx::mfma_epsilon(g.k_pad);
 
@@ -503,8 +505,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
                                                c->q_bad.p + q0, s));
         size_t slot = 0;
         prof_begin(c, s, slot);
-        HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g.n_rowtiles,
-                                              g.KS, qn, g.n_lists, g.strip_tiles, s));
+        HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, s));
         prof_end(c, s, slot);
         HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, s));
         vfsx::MfmaRescoreArgs a{};
@@ -526,6 +527,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.row_base = c->row_base;
         a.id_base = c->id_base;
         a.strip_tiles = g.strip_tiles;
+        a.wm = g.wm;
         HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
     }
     HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -647,6 +649,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
+        c->mfma_wm = env_u64("VFSX_MFMA_WM", 4) == 2 ? 2u : 4u;
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)

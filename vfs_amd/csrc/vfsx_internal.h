@@ -77,13 +77,14 @@ hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq
 struct MfmaGeometry {
     uint32_t k_pad;      // dim rounded up to 64
     uint32_t KS;         // k_pad / 16 fragment k-steps
-    uint32_t n_rowtiles; // ceil(n_rows / 128)
+    uint32_t wm;         // waves along M (2 or 4): workgroup tile = 64*wm rows x 128 queries
+    uint32_t n_rowtiles; // ceil(n_rows / (64*wm))
     uint32_t strip_tiles; // row tiles per strip (1..32)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
-    uint32_t n_lists;    // candidate lists per query = 4 * n_strips
+    uint32_t n_lists;    // candidate lists per query = 2 * wm * n_strips
     size_t mirror_bytes; // bf16 mirror of the corpus
 };
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim);
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t wm);
 float mfma_epsilon(uint32_t k_pad);
 
 struct MfmaRescoreArgs {
@@ -99,16 +100,15 @@ struct MfmaRescoreArgs {
     uint32_t n_rows, d_chunks, q_stride, k, kp;
     float eps;
     uint64_t row_base, id_base;
-    uint32_t strip_tiles;
+    uint32_t strip_tiles, wm;
 };
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
-                              uint32_t n_rowtiles, int *bad_flag, hipStream_t s);
+                              uint32_t n_rowgroups, int *bad_flag, hipStream_t s);
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
                                   int *q_bad, hipStream_t s);
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
-                                 uint32_t n_rowtiles, uint32_t KS, uint32_t nq, uint32_t n_lists,
-                                 uint32_t strip_tiles, hipStream_t s);
+                                 const MfmaGeometry &g, uint32_t nq, hipStream_t s);
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
                               hipStream_t s);
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);

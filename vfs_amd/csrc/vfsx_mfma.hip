@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "vfsx_device.h"
 #include "vfsx_internal.h"
@@ -35,7 +36,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr uint32_t kTileRows = 128;      // corpus rows per workgroup tile (M)
 constexpr uint32_t kTileQueries = 128;   // queries per workgroup tile (N)
 constexpr uint32_t kMaxStripTiles = 32;  // row tiles per strip (runtime, <= 32): up to 4096 rows share one top-2 per lane
 constexpr uint32_t kListDepth = 3;       // scores kept per candidate list
@@ -137,14 +137,32 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
     return c.b;
 }
 
-// grid = n_strips * n_qtiles workgroups of 256 threads (4 waves as 2(M) x 2(N), 64x64 per wave).
-__global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__restrict__ A,
-                                                             const uint4 *__restrict__ B,
-                                                             float *__restrict__ cand, uint32_t n_rows,
-                                                             uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
-                                                             uint32_t nq, uint32_t n_lists, uint32_t strip_tiles)
+// grid = n_strips * n_qtiles workgroups of 128*WM threads: 2*WM waves as WM(M) x 2(N), 64x64 per
+// wave, i.e. a (64*WM rows) x 128 queries tile.  K runs in steps of 64 through an NSTAGE-deep ring of
+// LDS buffers filled by global_load_lds: stage it+NSTAGE-1 is issued right after the barrier that
+// opens iteration `it`, a counted s_waitcnt vmcnt leaves NSTAGE-2 stages in flight across the (raw)
+// barrier, so HBM/L2 latency is covered by NSTAGE-1 K-steps of MFMA work instead of one.
+template <int WM, int NSTAGE>
+__global__ __launch_bounds__(128 * WM) void mfma_prefilter_kernel(const uint4 *__restrict__ A,
+                                                                  const uint4 *__restrict__ B,
+                                                                  float *__restrict__ cand, uint32_t n_rows,
+                                                                  uint32_t n_rowtiles, uint32_t KS,
+                                                                  uint32_t n_qtiles, uint32_t nq, uint32_t n_lists,
+                                                                  uint32_t strip_tiles)
 {
-    __shared__ __align__(16) uint4 lds[2][2][16 * 64]; // [buffer][A | B][16 units x 64 lanes] = 64 KiB
+    constexpr uint32_t WAVES = 2u * WM, TROWS = 64u * WM;
+    constexpr uint32_t A_UNITS = (TROWS / 32u) * 4u, B_UNITS = 16u, UNITS = A_UNITS + B_UNITS;
+    constexpr uint32_t G = UNITS / WAVES; // global_load_lds instructions per wave and stage
+    static_assert(UNITS % WAVES == 0, "stage units must split evenly over the waves");
+    // One __shared__ object per ring slot (WM=2: 2 x 32 KiB; WM=4: 3 x 48 KiB), and the K loop below is
+    // unrolled NSTAGE times so every slot index is a compile-time constant: hipcc orders a ds_read
+    // behind every LDS-DMA it cannot prove disjoint, i.e. with one dynamically indexed array it
+    // drains the whole ring (s_waitcnt vmcnt(0)) before the first fragment read of each K-step.
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+    __shared__ __align__(16) uint4 lds_s0[UNITS * 64];
+    __shared__ __align__(16) uint4 lds_s1[UNITS * 64];
+    __shared__ __align__(16) uint4 lds_s2[NSTAGE == 3 ? UNITS * 64 : 4];
+    auto slot = [&](int j) -> uint4 * { return j == 0 ? lds_s0 : (j == 1 ? lds_s1 : lds_s2); };
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -173,19 +191,18 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
     const uint32_t KT = KS >> 2;
     const uint32_t n_it = ntiles * KT;
 
-    auto stage = [&](uint32_t it, uint32_t buf) {
+    auto stage = [&](uint32_t it, uint4 *dst) {
         const uint32_t tile = tile0 + it / KT, kt = it % KT;
-        if (wave < 2) {
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t ua = wave * 8u + u, rg = ua >> 2, ks = ua & 3u;
-                glds16(A + ((size_t)(tile * 4u + rg) * KS + kt * 4u + ks) * 64u + lane, &lds[buf][0][ua * 64u]);
-            }
-        } else {
-#pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t ub = (wave - 2u) * 8u + u, qg = ub >> 2, ks = ub & 3u;
-                glds16(B + ((size_t)(qtile * 4u + qg) * KS + kt * 4u + ks) * 64u + lane, &lds[buf][1][ub * 64u]);
+        for (uint32_t u = 0; u < G; ++u) {
+            const uint32_t unit = wave * G + u; // wave-uniform
+            if (unit < A_UNITS) {
+                const uint32_t rg = unit >> 2, ks = unit & 3u;
+                glds16(A + ((size_t)(tile * (TROWS / 32u) + rg) * KS + kt * 4u + ks) * 64u + lane,
+                       dst + unit * 64u);
+            } else {
+                const uint32_t ub = unit - A_UNITS, qg = ub >> 2, ks = ub & 3u;
+                glds16(B + ((size_t)(qtile * 4u + qg) * KS + kt * 4u + ks) * 64u + lane, dst + unit * 64u);
             }
         }
     };
@@ -201,30 +218,44 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
     const float ninf = __uint_as_float(0xff800000u);
     float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf}; // running top-3 per query column
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (uint32_t it = 0; it < n_it; ++it) {
-        const uint32_t buf = it & 1u;
-        if (it + 1 < n_it)
-            stage(it + 1, buf ^ 1u);
+
+    // one K-step on ring slot J (compile-time): retire stage `it`, barrier, refill the slot freed by
+    // iteration it-1 with stage it+NSTAGE-1, then 16 MFMAs on slot J
+    auto kstep = [&](auto jc, uint32_t it) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int JW = (J + NSTAGE - 1) % NSTAGE;
+        const uint4 *rd = slot(J);
+        // retire stage `it` (this wave's part), leaving the younger stages in flight
+        if (NSTAGE > 2 && it + (NSTAGE - 2) < n_it) {
+            if (G * (NSTAGE - 2) == 6)
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (G * (NSTAGE - 2) == 8)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier(); // every wave's part of stage `it` has landed; slot JW is free
+        if (it + (NSTAGE - 1) < n_it)
+            stage(it + (NSTAGE - 1), slot(JW));
 #pragma unroll
         for (uint32_t ks = 0; ks < 4; ++ks) {
-            const bf16x8 a0 = as_bf16x8(lds[buf][0][((wave_m * 2u + 0u) * 4u + ks) * 64u + lane]);
-            const bf16x8 a1 = as_bf16x8(lds[buf][0][((wave_m * 2u + 1u) * 4u + ks) * 64u + lane]);
-            const bf16x8 b0 = as_bf16x8(lds[buf][1][((wave_n * 2u + 0u) * 4u + ks) * 64u + lane]);
-            const bf16x8 b1 = as_bf16x8(lds[buf][1][((wave_n * 2u + 1u) * 4u + ks) * 64u + lane]);
+            const bf16x8 a0 = as_bf16x8(rd[((wave_m * 2u + 0u) * 4u + ks) * 64u + lane]);
+            const bf16x8 a1 = as_bf16x8(rd[((wave_m * 2u + 1u) * 4u + ks) * 64u + lane]);
+            const bf16x8 b0 = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + 0u) * 4u + ks) * 64u + lane]);
+            const bf16x8 b1 = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + 1u) * 4u + ks) * 64u + lane]);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (it % KT == KT - 1u) {
-            // tile finished: fold its 64 scores per lane into the running top-2 of each query column.
+            // tile finished: fold its 64 scores per lane into the running top-3 of each query column.
             // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
             const uint32_t ts = it / KT;
-            const uint32_t tile_row0 = (tile0 + ts) * kTileRows;
-            const bool ragged = tile_row0 + kTileRows > n_rows;
+            const uint32_t tile_row0 = (tile0 + ts) * TROWS;
+            const bool ragged = tile_row0 + TROWS > n_rows;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -239,20 +270,29 @@ __global__ __launch_bounds__(256) void mfma_prefilter_kernel(const uint4 *__rest
                             if (row >= n_rows)
                                 sp = ninf;
                         }
-                        // insert sp into the sorted triple (m1 >= m2 >= m3): 5 VALU ops
-                        const float lo1 = fminf(m1[ni], sp);
+                        // insert sp into the sorted triple (m1 >= m2 >= m3) in 3 VALU ops: with a >= b,
+                        // med3(a, b, s) is what b becomes when s is inserted above or below it
+                        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
                         m1[ni] = fmaxf(m1[ni], sp);
-                        const float lo2 = fminf(m2[ni], lo1);
-                        m2[ni] = fmaxf(m2[ni], lo1);
-                        m3[ni] = fmaxf(m3[ni], lo2);
                         acc[mi][ni][r] = 0.0f;
                     }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+
+    if (0 < n_it)
+        stage(0, slot(0));
+    if (NSTAGE == 3 && 1 < n_it)
+        stage(1, slot(1));
+    for (uint32_t it = 0; it < n_it; it += NSTAGE) {
+        kstep(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < n_it)
+            kstep(std::integral_constant<int, 1>{}, it + 1);
+        if (NSTAGE == 3 && it + 2 < n_it)
+            kstep(std::integral_constant<int, 2>{}, it + 2);
     }
 
-    const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
+    const uint32_t list = strip * (2u * WM) + wave_m * 2u + (lane >> 5);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const uint32_t q = qtile * kTileQueries + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
@@ -316,14 +356,14 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
 }
 
 // ---- exact re-score + safety check ----------------------------------------------------------------
-__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles)
+__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles, uint32_t wm)
 {
     const uint32_t list = (uint32_t)comp;
     score = -key_dist((uint32_t)(comp >> 32));
     const uint32_t idx = __float_as_uint(score) & kIdxMask;
     const uint32_t ts = idx >> 5, mi = (idx >> 4) & 1u, r = idx & 15u;
-    const uint32_t strip = list >> 2, wave_m = (list >> 1) & 1u, half = list & 1u;
-    return (strip * strip_tiles + ts) * kTileRows + wave_m * 64u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+    const uint32_t strip = list / (2u * wm), wave_m = (list % (2u * wm)) >> 1, half = list & 1u;
+    return (strip * strip_tiles + ts) * (64u * wm) + wave_m * 64u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
 }
 
 template <int DTYPE, typename TopK>
@@ -332,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, float eps, uint64_t row_base, uint64_t id_base,
-    uint32_t strip_tiles)
+    uint32_t strip_tiles, uint32_t wm)
 {
     constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
     extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)]
@@ -364,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     float score = 0.0f;
     uint32_t row = 0;
     if (valid)
-        row = cand_row(comp_a, score, strip_tiles);
+        row = cand_row(comp_a, score, strip_tiles, wm);
     const bool in_range = valid && row < n_rows;
     if (wave * 64u < kp) { // wave-uniform: this wave has candidates
         const uint32_t r = in_range ? row : 0u;
@@ -468,9 +508,9 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
 
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
-                              uint32_t n_rowtiles, int *bad_flag, hipStream_t s)
+                              uint32_t n_rowgroups, int *bad_flag, hipStream_t s)
 {
-    const uint64_t total_units = (uint64_t)n_rowtiles * 4u * KS;
+    const uint64_t total_units = (uint64_t)n_rowgroups * KS; // 32-row groups, rows padded to a multiple of 256
     const uint64_t threads = total_units * 64u;
     const uint64_t blocks = (threads + 255) / 256;
     if (blocks > 0x7fffffffull)
@@ -493,13 +533,16 @@ hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t 
 }
 
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
-                                 uint32_t n_rowtiles, uint32_t KS, uint32_t nq, uint32_t n_lists,
-                                 uint32_t strip_tiles, hipStream_t s)
+                                 const MfmaGeometry &g, uint32_t nq, hipStream_t s)
 {
     const uint32_t n_qtiles = (nq + kTileQueries - 1) / kTileQueries;
-    const uint32_t n_strips = (n_rowtiles + strip_tiles - 1) / strip_tiles;
-    hipLaunchKernelGGL(mfma_prefilter_kernel, dim3(n_strips * n_qtiles), dim3(256), 0, s, mirror,
-                       (const uint4 *)q_mirror, cand, n_rows, n_rowtiles, KS, n_qtiles, nq, n_lists, strip_tiles);
+    const dim3 grid(g.n_strips * n_qtiles);
+    if (g.wm == 4)
+        hipLaunchKernelGGL((mfma_prefilter_kernel<4, 3>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror, cand,
+                           n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+    else
+        hipLaunchKernelGGL((mfma_prefilter_kernel<2, 2>), grid, dim3(256), 0, s, mirror, (const uint4 *)q_mirror, cand,
+                           n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
     return hipGetLastError();
 }
 
@@ -525,26 +568,30 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     if (dtype == VFSX_I8)
         hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_I8, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
-                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles);
+                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm);
     else
         hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_F32, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
-                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles);
+                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm);
     return hipGetLastError();
 }
 
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim)
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t wm)
 {
     MfmaGeometry g;
+    g.wm = wm == 2 ? 2u : 4u; // waves along M: tile = 64*wm rows x 128 queries
+    const uint32_t tile_rows = 64u * g.wm;
     g.k_pad = (dim + 63u) / 64u * 64u;
     g.KS = g.k_pad / 16u;
-    g.n_rowtiles = (n_rows + kTileRows - 1) / kTileRows;
-    // aim for >= ~4096 candidate lists per query so that two rows above the safety margin rarely share
-    // one (small corpora get short strips -- and more workgroups), capped at 32 tiles (5 index bits)
-    g.strip_tiles = std::min<uint32_t>(kMaxStripTiles, std::max<uint32_t>(1u, g.n_rowtiles / 1024u));
+    g.n_rowtiles = (n_rows + tile_rows - 1) / tile_rows;
+    // aim for >= ~4096 candidate lists per query so that three rows above the safety margin rarely share
+    // one (small corpora get short strips -- and more workgroups); at most 4096 rows per strip and
+    // 32 tiles (5 index bits)
+    const uint32_t max_tiles = std::min<uint32_t>(kMaxStripTiles, 4096u / tile_rows);
+    g.strip_tiles = std::min<uint32_t>(max_tiles, std::max<uint32_t>(1u, (n_rows / tile_rows) * (2u * g.wm) / 4096u));
     g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
-    g.n_lists = g.n_strips * 4u;
-    g.mirror_bytes = (size_t)g.n_rowtiles * kTileRows * g.k_pad * 2u;
+    g.n_lists = g.n_strips * 2u * g.wm;
+    g.mirror_bytes = (size_t)((n_rows + 255u) / 256u) * 256u * g.k_pad * 2u; // rows padded for either tile
     return g;
 }
 
