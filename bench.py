@@ -34,6 +34,8 @@ WORKLOADS = {
     "c2": (1_000_000, 768, False, 1, "C2 1Mx768 f32 Cosine exact top-10, single-query scan"),
     "c2e": (1_000_000, 768, False, 0, "1Mx768 f32 Euclidean exact top-10, single-query scan"),
     "c3": (10_000_000, 128, True, 0, "C3 10Mx128 int8 QuantizedVector Euclidean exact top-10"),
+    "c3i": (10_000_000, 128, True, 4, "10Mx128 int8, LABELLED integer-domain fast mode (extension, not the reference's "
+                                       "arithmetic; SURVEY 8a A6(ii)), exact top-10"),
     "c1": (100_000, 128, False, 2, "C1 100kx128 f32 SimdEuclidean exact top-10"),
     "c5": (12_500_000, 768, False, 0, "C5 shard 12.5Mx768 f32 Euclidean (100Mx768 over 8 GPUs)"),
     "c4": (10_000_000, 1024, False, 1, "C4 4096-query batch x 10Mx1024 Cosine as Q.X^T on bf16 MFMA + fused top-k, "
@@ -185,6 +187,21 @@ def main() -> int:
         tflops = flops / (avg_ms * 1e-3) / 1e12
         mq, mf = corpus.mfma_stats()
 
+    # per-query latency (>=100 back-to-back distinct queries, median), single mode only
+    latency = None
+    if args.mode == "single" and world == 1:
+        n_lat = min(128, n_q)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_lat + 1)]
+        stream = torch.cuda.current_stream().cuda_stream
+        evs[0].record()
+        for j in range(n_lat):
+            corpus.search_device(d_q[j].data_ptr(), 1, k, metric, d_local[0].data_ptr(), stream)
+            evs[j + 1].record()
+        torch.cuda.synchronize()
+        lat = sorted(evs[j].elapsed_time(evs[j + 1]) for j in range(n_lat))
+        latency = {"queries": n_lat, "median": round(lat[n_lat // 2], 4), "p99": round(lat[min(n_lat - 1, int(n_lat * 0.99))], 4),
+                   "min": round(lat[0], 4), "unit": "ms", "what": "device time per query (scan + select), back-to-back"}
+
     queries = args.steps * qps_step
     qps_global = queries / elapsed
     value = qps_global * world  # shard scans per second (see module docstring)
@@ -203,15 +220,23 @@ def main() -> int:
         "data": "synthetic",
         "config": {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k, "storage": "i8 (QuantizedVector, dequantized on read)" if quantize else "f32",
                    "queries_per_step": qps_step, "mode": args.mode, "metric_fn": ["euclidean", "cosine", "simd_euclidean",
-                                                                "simd_cosine"][metric],
+                                                                "simd_cosine", "euclidean_i8_domain"][metric],
                    "sharding": f"row-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
         "qps_global": round(qps_global, 3),
         "hbm_gbps_aggregate": round(qps_global * algo_bytes * world / 1e9, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args.workload, rows),
-                     "kernel": "scan_kernel", "avg_kernel_ms": round(avg_ms, 5),
+                     "kernel": "scan_i8dom_kernel" if metric == 4 else "scan_kernel", "avg_kernel_ms": round(avg_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches)},
     }
+    if metric == 4:
+        out["dtype"] = "int32 dot4 on i8 (integer-domain extension) + f32 sqrt/div"
+    if latency:
+        out["query_latency_ms"] = latency
+    props = torch.cuda.get_device_properties(local_rank)
+    out["device"] = {"name": props.name, "arch": getattr(props, "gcnArchName", ""), "cus": props.multi_processor_count,
+                     "hbm_gib": round(props.total_memory / 2**30, 1),
+                     "peak_source": "MI355X_MICROARCH.md (8 TB/s HBM3E, 2.5 PFLOP/s dense bf16)"}
     if mfma:
         out["roofline"] = {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -267,10 +292,30 @@ def cpu_baseline(args, rows, dim, quantize, metric, k):
         c_oracle.topk_scan(x, q, metric, k)
     dt = time.perf_counter() - t0
     rows_per_s = n * len(qs) / dt
-    return {"value": round(rows_per_s / rows, 4), "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"{len(qs)} queries x first {n} rows of the same synthetic corpus "
-                      f"({dt:.1f} s of CPU), rows/s scaled to the full {rows}-row corpus",
-            "rows_per_s": round(rows_per_s, 1)}
+    out = {"value": round(rows_per_s / rows, 4), "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": f"{len(qs)} queries x first {n} rows of the same synthetic corpus "
+                     f"({dt:.1f} s of CPU), rows/s scaled to the full {rows}-row corpus",
+           "rows_per_s": round(rows_per_s, 1)}
+    # context only: a 64-lane-chunked, vectorised restatement of the
+    # reference's core::simd path (oracle/cpu_context.c; different summation order, so NOT the
+    # parity arithmetic), on one core and on this process's cores (capped at 16)
+    if metric > 3:
+        return out
+    try:
+        threads = min(16, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        threads = min(16, os.cpu_count() or 1)
+    ctx = {"arithmetic": "64-lane chunked sums (not the reference's order); timing context only",
+           "avx2": bool(c_oracle.lib().vfsc_have_avx2())}
+    for label, nt, nq in (("simd_chunked_1core", 1, max(8, len(qs) // 2)), ("simd_chunked_allcores", threads, len(qs))):
+        c_oracle.chunked_scan(x[:1024], qs[0], metric, k, nt)
+        t0 = time.perf_counter()
+        for q in qs[:nq]:
+            c_oracle.chunked_scan(x, q, metric, k, nt)
+        dtc = time.perf_counter() - t0
+        ctx[label] = {"value": round(n * nq / dtc / rows, 4), "unit": "queries/s", "cores": nt}
+    out["context"] = ctx
+    return out
 
 
 if __name__ == "__main__":

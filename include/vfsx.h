@@ -63,7 +63,16 @@ typedef enum vfsx_metric {
     VFSX_EUCLIDEAN = 0,
     VFSX_COSINE = 1,
     VFSX_SIMD_EUCLIDEAN = 2,
-    VFSX_SIMD_COSINE = 3
+    VFSX_SIMD_COSINE = 3,
+    /* EXTENSION, not a reference DistanceMethod ("A6 decision" (ii)): the
+     * labelled integer-domain fast mode for VFSX_I8 corpora.  The query is quantized with
+     * the reference's own rule (VFSVector::as_i8_vec(Some(scale)), vector.rs:293-302 ->
+     * Vector::quantize, vector.rs:94-108), S = sum (qi - x)^2 is exact in integers and
+     * dist = sqrt(S as f32) / scale.  Its results differ from the reference's (the query's
+     * quantization error), so it is never selected implicitly; VFSX_EUCLIDEAN on an int8
+     * corpus stays the reference-faithful definition.  dim <= 32768; f32 corpora are
+     * rejected with VFSX_ERR_INVALID_VECTOR. */
+    VFSX_EUCLIDEAN_I8DOMAIN = 4
 } vfsx_metric;
 
 /* One ranked hit as produced on the device.  `row` is the global scan position

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libvfs_oracle.so")
 
 EUCLIDEAN, COSINE, SIMD_EUCLIDEAN, SIMD_COSINE = 0, 1, 2, 3
+EUCLIDEAN_I8DOMAIN = 4  # product extension (labelled fast mode), not a reference DistanceMethod
 
 
 def build() -> str:
@@ -41,6 +42,10 @@ def _load():
     lib.vfso_fill_synthetic_i8.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                            C.c_float, i8p]
     lib.vfso_simd_width_supported.argtypes = [C.c_uint32]
+    lib.vfsc_chunked_scan.restype = C.c_uint64
+    lib.vfsc_chunked_scan.argtypes = [f32p, i8p, C.c_float, C.c_uint64, C.c_uint32, f32p, C.c_int,
+                                      C.c_uint64, C.c_int, u64p, f32p]
+    lib.vfsc_have_avx2.restype = C.c_int
     return lib
 
 
@@ -111,6 +116,24 @@ def topk_scan(rows, query, metric, limit, ids=None, scale=127.0):
                              _p(query, C.c_float), metric, limit, _p(oi, C.c_uint64),
                              _p(od, C.c_float), _p(op, C.c_uint64))
     return oi[:m].copy(), od[:m].copy(), op[:m].copy()
+
+
+def chunked_scan(rows, query, metric, limit, n_threads=1, scale=127.0):
+    """cpu_context.c: 64-lane-chunked (vectorised, optionally threaded) scan.  NOT the
+    reference's summation order -- timing context for bench.py only.  Returns (pos, dist)."""
+    query = np.ascontiguousarray(query, np.float32)
+    n, d = rows.shape
+    op = np.empty(max(limit, 1), np.uint64)
+    od = np.empty(max(limit, 1), np.float32)
+    if rows.dtype == np.int8:
+        rows = np.ascontiguousarray(rows)
+        f, i8 = None, _p(rows, C.c_int8)
+    else:
+        rows = np.ascontiguousarray(rows, np.float32)
+        f, i8 = _p(rows, C.c_float), None
+    m = lib().vfsc_chunked_scan(f, i8, float(scale), n, d, _p(query, C.c_float), metric, limit,
+                                int(n_threads), _p(op, C.c_uint64), _p(od, C.c_float))
+    return op[:m].copy(), od[:m].copy()
 
 
 def all_distances(rows, query, metric, scale=127.0):

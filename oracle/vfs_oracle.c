@@ -139,6 +139,24 @@ void vfso_dequantize(const int8_t *v, uint64_t n, float scale, float *out)
     }
 }
 
+/*
+ * EXTENSION (not a reference DistanceMethod; SURVEY.md 8a "A6 decision" (ii)): the
+ * integer-domain Euclidean distance of the product's labelled fast mode
+ * VFSX_EUCLIDEAN_I8DOMAIN (= metric 4).  `qi` is the query quantized by the reference's
+ * own rule, VFSVector::as_i8_vec(Some(scale)) -> Vector::quantize (vector.rs:293-302,
+ * 94-108), i.e. vfso_quantize(q, d, 1, scale, qi).  S is exact (order independent);
+ * the two f32 operations are correctly rounded.
+ */
+float vfso_dist_euclidean_i8dom(const int8_t *qi, const int8_t *x, uint32_t d, float scale)
+{
+    uint32_t S = 0;
+    for (uint32_t j = 0; j < d; ++j) {
+        int32_t t = (int32_t)qi[j] - (int32_t)x[j];
+        S += (uint32_t)(t * t);
+    }
+    return sqrtf((float)S) / scale;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Ranking: vfs/src/vfs/rank.rs:119-186                                       */
 /* ------------------------------------------------------------------------- */
@@ -244,18 +262,28 @@ uint64_t vfso_topk_scan(const float *rows_f32, const int8_t *rows_i8, float scal
 {
     if (limit == 0)
         return 0;
+    if (metric == 4 && !rows_i8)
+        return 0;
     vfso_hit *res = (vfso_hit *)malloc((size_t)limit * sizeof(vfso_hit));
     float *tmp = rows_i8 ? (float *)malloc((size_t)d * sizeof(float)) : NULL;
+    int8_t *qi = NULL;
+    if (metric == 4) {
+        qi = (int8_t *)malloc(d ? d : 1);
+        vfso_quantize(query, d, 1, scale, qi);
+    }
     size_t len = 0;
     for (uint64_t r = 0; r < n_rows; ++r) {
-        const float *x;
-        if (rows_i8) {
+        const float *x = NULL;
+        if (metric == 4) {
+            ;
+        } else if (rows_i8) {
             vfso_dequantize(rows_i8 + (size_t)r * d, d, scale, tmp);
             x = tmp;
         } else {
             x = rows_f32 + (size_t)r * d;
         }
-        float dist = vfso_distance(metric, query, x, d);
+        float dist = metric == 4 ? vfso_dist_euclidean_i8dom(qi, rows_i8 + (size_t)r * d, d, scale)
+                                 : vfso_distance(metric, query, x, d);
         if (len == limit && !(dist < res[len - 1].dist))
             continue;
         size_t j = len < limit ? len : len - 1;
@@ -277,6 +305,7 @@ uint64_t vfso_topk_scan(const float *rows_f32, const int8_t *rows_i8, float scal
     }
     free(res);
     free(tmp);
+    free(qi);
     return (uint64_t)len;
 }
 
@@ -285,6 +314,15 @@ void vfso_all_distances(const float *rows_f32, const int8_t *rows_i8, float scal
                         uint32_t d, const float *query, int metric, float *out)
 {
     float *tmp = rows_i8 ? (float *)malloc((size_t)d * sizeof(float)) : NULL;
+    if (metric == 4) {
+        int8_t *qi = (int8_t *)malloc(d ? d : 1);
+        vfso_quantize(query, d, 1, scale, qi);
+        for (uint64_t r = 0; rows_i8 && r < n_rows; ++r)
+            out[r] = vfso_dist_euclidean_i8dom(qi, rows_i8 + (size_t)r * d, d, scale);
+        free(qi);
+        free(tmp);
+        return;
+    }
     for (uint64_t r = 0; r < n_rows; ++r) {
         const float *x;
         if (rows_i8) {

@@ -79,6 +79,17 @@ def dequantize(q: np.ndarray, scale=127.0) -> np.ndarray:
     return (np.asarray(q, dtype=np.int8).astype(F32) / F32(scale)).astype(F32)
 
 
+def distances_i8dom(rows_i8: np.ndarray, query: np.ndarray, scale=127.0) -> np.ndarray:
+    """EXTENSION (product metric 4, not a reference DistanceMethod):
+    query quantized by the reference's rule (vector.rs:293-302 -> 94-108), S exact in
+    integers, dist = sqrt(S as f32) / scale."""
+    x = np.asarray(rows_i8, dtype=np.int8).astype(np.int64)
+    qi = quantize(np.asarray(query, dtype=F32), scale).astype(np.int64)
+    S = ((qi[None, :] - x) ** 2).sum(axis=1)
+    assert S.max(initial=0) < 2 ** 32
+    return (np.sqrt(S.astype(np.uint32).astype(F32)).astype(F32) / F32(scale)).astype(F32)
+
+
 def exact_search(rows, query, metric, batch, limit=5, ids=None):
     """rank.rs:119-186 mirrored literally (stable sort, truncate, retain), per batch.
 

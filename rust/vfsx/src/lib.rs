@@ -58,6 +58,8 @@ pub enum DistanceMethod {
     Cosine = 1,
     SimdEuclidean = 2,
     SimdCosine = 3,
+    /// Extension (VFSX_EUCLIDEAN_I8DOMAIN): integer-domain fast mode, quantized corpora only.
+    EuclideanI8Domain = 4,
 }
 
 /// Device-resident stand-in for the part of `VFSManager` the scan reads.

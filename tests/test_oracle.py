@@ -99,3 +99,54 @@ def test_synth_generators_agree():
     assert (bits(a) == bits(on.synth_f32(synth.CORPUS_SEED, 12345, 40, 33))).all()
     assert (bits(a) == bits(synth.rows_f32(synth.CORPUS_SEED, 12345, 40, 33))).all()
     assert a.min() >= -1.0 and a.max() < 1.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "i8"])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_cpu_context_scan_tracks_oracle(dtype, metric):
+    """oracle/cpu_context.c is only a timing baseline (chunked sums), but it must rank the same
+    corpus sensibly: distances within 1e-5 of the bit-faithful port, same rows where the
+    port's neighbours are separated by more than that, threaded == single-threaded."""
+    d = 200  # exercises the 64-lane body and the scalar tail
+    x = co.synth_f32(11, 0, 5000, d)
+    if dtype == "i8":
+        x = co.quantize(x)
+    q = co.synth_f32(12, 0, 1, d)[0]
+    _, dist, pos = co.topk_scan(x, q, metric, 10)
+    p1, d1 = co.chunked_scan(x, q, metric, 10, 1)
+    p3, d3 = co.chunked_scan(x, q, metric, 10, 3)
+    assert np.array_equal(p1, p3) and np.array_equal(d1, d3)
+    assert np.allclose(d1, dist, rtol=1e-5, atol=1e-6)
+    if np.min(np.diff(dist)) > 1e-5:
+        assert np.array_equal(p1, pos)
+
+
+@pytest.mark.parametrize("d", [1, 16, 40, 128, 515])
+def test_i8dom_extension_c_vs_numpy(d):
+    """Metric 4 (integer-domain fast mode, an extension -- not the reference's arithmetic): the two
+    restatements agree bit for bit, ties resolve by scan position, and it differs from the
+    reference-faithful distance only by the query's quantization error."""
+    x = co.synth_i8(21, 0, 3000, d)
+    x[100] = x[7]  # an exact duplicate: tie broken by position
+    q = co.synth_f32(22, 0, 1, d)[0]
+    all_c = co.all_distances(x, q, 4)
+    all_n = on.distances_i8dom(x, q)
+    assert np.array_equal(all_c.view(np.uint32), all_n.view(np.uint32))
+    ids, dist, pos = co.topk_scan(x, q, 4, 25)
+    order = np.argsort(all_n, kind="stable")[:25]
+    assert np.array_equal(pos, order.astype(np.uint64))
+    assert np.array_equal(dist.view(np.uint32), all_n[order].view(np.uint32))
+    faithful = co.all_distances(x, q, 0)
+    assert np.max(np.abs(faithful - all_c)) <= np.sqrt(d) * (0.5 / 127.0) + 1e-5
+
+
+def test_i8dom_kats():
+    # query [1,2,3,4] saturates to [127]*4 (vector.rs:106, no clamp with Some(scale)); row = the same
+    x = np.array([[127, 127, 127, 127], [0, 0, 0, 0], [-128, 127, 0, 1]], np.int8)
+    q = np.array([1, 2, 3, 4], np.float32)
+    got = co.all_distances(x, q, 4)
+    want = np.array([0.0, np.sqrt(np.float32(4 * 127 * 127)) / np.float32(127.0),
+                     np.sqrt(np.float32(255 * 255 + 127 * 127 + 126 * 126)) / np.float32(127.0)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # f32 rows are not a valid operand for this mode
+    assert len(co.topk_scan(np.zeros((4, 4), np.float32), q, 4, 2)[0]) == 0

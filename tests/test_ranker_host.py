@@ -26,8 +26,10 @@ class StubCorpus:
 
 def test_enum_order_matches_reference():
     # rank.rs:67-72
-    assert [m.name for m in DistanceMethod] == ["Euclidean", "Cosine", "SimdEuclidean", "SimdCosine"]
-    assert [int(m) for m in DistanceMethod] == [0, 1, 2, 3]
+    # the reference's four methods keep its declaration order; the one extension comes after them
+    assert [m.name for m in DistanceMethod][:4] == ["Euclidean", "Cosine", "SimdEuclidean", "SimdCosine"]
+    assert [int(m) for m in DistanceMethod] == [0, 1, 2, 3, 4]
+    assert DistanceMethod.EuclideanI8Domain == 4 and len(DistanceMethod) == 5
     # tcp.rs:388-394
     assert DistanceMethod.from_request("cosine") is DistanceMethod.Cosine
     assert DistanceMethod.from_request("simd_euclidean") is DistanceMethod.SimdEuclidean

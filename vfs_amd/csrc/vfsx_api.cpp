@@ -343,8 +343,13 @@ void prof_collect(vfsx_corpus *c)
 void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
                          vfsx_hit *d_hits, hipStream_t s)
 {
-    if (metric < VFSX_EUCLIDEAN || metric > VFSX_SIMD_COSINE)
+    if (metric < VFSX_EUCLIDEAN || metric > VFSX_EUCLIDEAN_I8DOMAIN)
         fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
+    const bool i8dom = metric == VFSX_EUCLIDEAN_I8DOMAIN;
+    if (i8dom && c->dtype != VFSX_I8)
+        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain distance needs a quantized (int8) corpus");
+    if (i8dom && c->dim > 32768u)
+        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain distance supports dim <= 32768");
     if (k == 0 || k > VFSX_MAX_K)
         fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
     if (nq == 0)
@@ -359,7 +364,14 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
     const bool need_pad = (q_stride_pad != c->dim);
     const float *q_ptr = d_queries;
     uint32_t q_stride = c->dim;
-    if (need_pad) {
+    if (i8dom) { // quantize the queries on the device; q_pad doubles as the packed-dword buffer
+        const uint32_t n_words = c->d_chunks * 4u;
+        q_stride = n_words + 4u;
+        c->q_pad.reserve((size_t)nq * q_stride);
+        HIP_CHECK(vfsx::launch_query_quantize(d_queries, nq, c->dim, c->scale, (uint32_t *)c->q_pad.p, n_words,
+                                              q_stride, s));
+        q_ptr = c->q_pad.p;
+    } else if (need_pad) {
         c->q_pad.reserve((size_t)nq * q_stride_pad);
         HIP_CHECK(vfsx::launch_query_pad(d_queries, nq, c->dim, c->q_pad.p, q_stride_pad, s));
         q_ptr = c->q_pad.p;
@@ -379,7 +391,7 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
     // queries per corpus pass: as many as the batch offers (max 8), while the workgroup's
     // LDS (lists + staged queries [+ 32 KiB LUT for int8]) stays within 64 KiB
     int nq_per_pass = 1;
-    {
+    if (!i8dom) {
         const uint32_t cap = (uint32_t)std::min<uint64_t>(8, c->nq_per_pass_max);
         const size_t lds_static = c->dtype == VFSX_I8 ? 32768 : 16;
         for (int cand : {8, 4, 2}) {
@@ -416,7 +428,10 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
             a.n_lists = grid_x;
             size_t slot = 0;
             prof_begin(c, s, slot);
-            HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
+            if (i8dom)
+                HIP_CHECK(vfsx::launch_scan_i8dom(a, qn, grid_x, nt != 0, c->scale, s));
+            else
+                HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
             prof_end(c, s, slot);
         }
         SelectArgs sa{};
@@ -555,7 +570,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
                         vfsx_hit *d_hits, hipStream_t s)
 {
-    if (metric < VFSX_EUCLIDEAN || metric > VFSX_SIMD_COSINE)
+    if (metric < VFSX_EUCLIDEAN || metric > VFSX_EUCLIDEAN_I8DOMAIN)
         fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
     if (k == 0 || k > VFSX_MAX_K)
         fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));

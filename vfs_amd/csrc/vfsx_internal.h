@@ -73,6 +73,13 @@ hipError_t launch_get_rows(int dtype, const uint4 *corpus, uint32_t dim, uint32_
 hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
                              vfsx_hit *d_out, hipStream_t s);
 
+// ---- integer-domain Euclidean on int8 corpora (vfsx_i8dom.hip; VFSX_EUCLIDEAN_I8DOMAIN) ----------
+// d_qw[nq][qw_stride]: n_words packed quantized dwords, then sum qi^2; qw_stride % 4 == 0
+hipError_t launch_query_quantize(const float *d_queries, uint32_t nq, uint32_t dim, float scale, uint32_t *d_qw,
+                                 uint32_t n_words, uint32_t qw_stride, hipStream_t s);
+// a.queries = d_qw (reinterpreted), a.q_stride = qw_stride
+hipError_t launch_scan_i8dom(const ScanArgs &a, uint32_t nq, uint32_t grid_x, bool nt, float scale, hipStream_t s);
+
 // ---- many-query batches on the matrix cores (vfsx_mfma.hip) ---------------------------------
 struct MfmaGeometry {
     uint32_t k_pad;      // dim rounded up to 64

@@ -28,7 +28,8 @@ inline void check(int rc)
 }
 
 enum class SearchType { Exact, Approximate };                                   // rank.rs:61-64
-enum class DistanceMethod { Euclidean, Cosine, SimdEuclidean, SimdCosine };     // rank.rs:67-72
+enum class DistanceMethod { Euclidean, Cosine, SimdEuclidean, SimdCosine,     // rank.rs:67-72
+                            EuclideanI8Domain /* extension: VFSX_EUCLIDEAN_I8DOMAIN, int8 corpora only */ };
 
 // The vector set the scan reads, in scan order (what load_batch yields,
 // storage_manager.rs:166-217), resident in HBM.

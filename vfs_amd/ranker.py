@@ -27,13 +27,17 @@ class DistanceMethod(enum.IntEnum):  # rank.rs:67-72 (declaration order)
     Cosine = 1
     SimdEuclidean = 2
     SimdCosine = 3
+    # EXTENSION (include/vfsx.h VFSX_EUCLIDEAN_I8DOMAIN): integer-domain fast mode for quantized
+    # corpora; not one of the reference's methods and never chosen implicitly
+    EuclideanI8Domain = 4
 
     @staticmethod
     def from_request(name: Optional[str]) -> "DistanceMethod":
         """tcp.rs:388-394: unknown / missing -> Euclidean."""
         return {"cosine": DistanceMethod.Cosine, "euclidean": DistanceMethod.Euclidean,
                 "simd_cosine": DistanceMethod.SimdCosine,
-                "simd_euclidean": DistanceMethod.SimdEuclidean}.get(name or "", DistanceMethod.Euclidean)
+                "simd_euclidean": DistanceMethod.SimdEuclidean,
+                "euclidean_i8_domain": DistanceMethod.EuclideanI8Domain}.get(name or "", DistanceMethod.Euclidean)
 
 
 SIMD_WIDTHS = (2, 4, 8, 16, 32, 64)  # rank.rs:303,307
