@@ -163,7 +163,7 @@ struct vfsx_corpus {
     int *d_mirror_bad = nullptr; // device flag: a row with zero / non-finite norm exists
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 64;
-    uint32_t mfma_wm = 4; // prefilter tile: 256 rows x 128 queries, 3-stage ring (2 = 128 x 128, 2 stages)
+    uint32_t mfma_wm = 0; // prefilter kernel variant (vfsx::mfma_geometry): 0 = 256 x 256 tile, 4-slot ring
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
     DeviceBuf<float> cand;
@@ -503,8 +503,8 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     }
     // queries per round: candidate workspace (3 floats per list and query) capped at 1 GiB
     const uint64_t per_q = (uint64_t)g.n_lists * 3u * sizeof(float);
-    uint32_t q_round = (uint32_t)std::max<uint64_t>(128, std::min<uint64_t>(nq, (1ull << 30) / per_q) / 128u * 128u);
-    q_round = std::min<uint32_t>(q_round, (nq + 127u) / 128u * 128u);
+    uint32_t q_round = (uint32_t)std::max<uint64_t>(256, std::min<uint64_t>(nq, (1ull << 30) / per_q) / 256u * 256u);
+    q_round = std::min<uint32_t>(q_round, (nq + 255u) / 256u * 256u);
     c->cand.reserve((size_t)q_round * 3u * g.n_lists);
     c->sel.reserve((size_t)q_round * kp);
     c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
@@ -514,7 +514,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 
     for (uint32_t q0 = 0; q0 < nq; q0 += q_round) {
         const uint32_t qn = std::min(q_round, nq - q0);
-        const uint32_t qn_pad = (qn + 127u) / 128u * 128u;
+        const uint32_t qn_pad = (qn + 255u) / 256u * 256u;
         HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * 2u, s));
         HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
                                                c->q_bad.p + q0, s));
@@ -543,6 +543,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.id_base = c->id_base;
         a.strip_tiles = g.strip_tiles;
         a.wm = g.wm;
+        a.wave_rows = g.wave_rows;
         HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
     }
     HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -664,7 +665,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
-        c->mfma_wm = env_u64("VFSX_MFMA_WM", 4) == 2 ? 2u : 4u;
+        c->mfma_wm = (uint32_t)std::min<uint64_t>(3, env_u64("VFSX_MFMA_VARIANT", 0));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)

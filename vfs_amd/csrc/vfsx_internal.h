@@ -84,14 +84,17 @@ hipError_t launch_scan_i8dom(const ScanArgs &a, uint32_t nq, uint32_t grid_x, bo
 struct MfmaGeometry {
     uint32_t k_pad;      // dim rounded up to 64
     uint32_t KS;         // k_pad / 16 fragment k-steps
-    uint32_t wm;         // waves along M (2 or 4): workgroup tile = 64*wm rows x 128 queries
-    uint32_t n_rowtiles; // ceil(n_rows / (64*wm))
+    uint32_t variant;    // prefilter kernel, see mfma_geometry()
+    uint32_t wm;         // waves along M (2 or 4)
+    uint32_t wave_rows;  // rows per wave tile (64 or 128): workgroup tile = wave_rows*wm rows
+    uint32_t tile_queries; // queries per workgroup tile (128 or 256)
+    uint32_t n_rowtiles; // ceil(n_rows / (wave_rows*wm))
     uint32_t strip_tiles; // row tiles per strip (1..32)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
     uint32_t n_lists;    // candidate lists per query = 2 * wm * n_strips
     size_t mirror_bytes; // bf16 mirror of the corpus
 };
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t wm);
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t variant);
 float mfma_epsilon(uint32_t k_pad);
 
 struct MfmaRescoreArgs {
@@ -107,7 +110,7 @@ struct MfmaRescoreArgs {
     uint32_t n_rows, d_chunks, q_stride, k, kp;
     float eps;
     uint64_t row_base, id_base;
-    uint32_t strip_tiles, wm;
+    uint32_t strip_tiles, wm, wave_rows;
 };
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,

@@ -127,6 +127,20 @@ __device__ __forceinline__ void glds16(const uint4 *g, uint4 *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// Same, with the LDS destination laundered through an empty asm so that hipcc cannot tell which
+// __shared__ object the DMA writes.  Its waitcnt pass orders every ds_read of an object behind the
+// pending LDS-DMAs it can attribute to that object -- and, unable to count them in order, does so
+// with s_waitcnt vmcnt(0), i.e. it drains the whole ring once per unrolled round and serialises the
+// freshly issued stage with the MFMAs.  The ring's own protocol (counted vmcnt + s_barrier before a
+// slot is read, barrier before it is refilled) is what makes the reads safe, not the compiler's.
+__device__ __forceinline__ void glds16_untracked(const uint4 *g, uint4 *lds_wave_base)
+{
+    uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base;
+    asm volatile("" : "+v"(a));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)a, 16, 0, 0);
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
 {
     union {
@@ -304,6 +318,193 @@ __global__ __launch_bounds__(128 * WM) void mfma_prefilter_kernel(const uint4 *_
     }
 }
 
+// ---- prefilter GEMM, 256 rows x 256 queries per workgroup (the default) ---------------------------
+// The 256 x 128 kernel above moves (256+128) x 2 B per 2 x 256 x 128 flop of K-slice through
+// L2 -> LDS = 85 flop/B, and at ~0.9 PFLOP/s that is ~11 TB/s of global_load_lds traffic -- the
+// same figure the 128 x 128 tile (64 flop/B, 0.72 PFLOP/s) hit: both are bound by the L2 -> LDS
+// fill rate, not by the matrix cores.  This tile raises it to 128 flop/B: 8 waves as 2 (M) x 4 (N),
+// 128 rows x 64 queries per wave (4 x 2 MFMA tiles, 128 accumulator registers), 6 fragment reads
+// per 8 MFMAs.  K runs in steps of 16*KU through an NSTAGE-deep ring (KU=2: 4 x 32 KiB,
+// KU=4: 2 x 64 KiB), same counted-vmcnt protocol as above.
+// Candidate lists: list = strip * 4 + wave_m * 2 + (lane >> 5); row position in the 10 low
+// mantissa bits = tile-in-strip (4 bits) | mi (2 bits) | accumulator register (4 bits).
+template <int KU, int NSTAGE>
+__global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__restrict__ A,
+                                                                const uint4 *__restrict__ B,
+                                                                float *__restrict__ cand, uint32_t n_rows,
+                                                                uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
+                                                                uint32_t nq, uint32_t n_lists, uint32_t strip_tiles)
+{
+    constexpr uint32_t TROWS = 256u, TQ = 256u;
+    constexpr uint32_t A_UNITS = 8u * KU, UNITS = 16u * KU;
+    constexpr uint32_t G = 2u * KU; // global_load_lds instructions per wave and stage
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+    static_assert((size_t)NSTAGE * UNITS * 1024u <= 160u * 1024u, "ring exceeds the LDS");
+    __shared__ __align__(16) uint4 lds_s0[UNITS * 64];
+    __shared__ __align__(16) uint4 lds_s1[UNITS * 64];
+    __shared__ __align__(16) uint4 lds_s2[NSTAGE > 2 ? UNITS * 64 : 4];
+    __shared__ __align__(16) uint4 lds_s3[NSTAGE > 3 ? UNITS * 64 : 4];
+    auto slot = [&](int j) -> uint4 * { return j == 0 ? lds_s0 : (j == 1 ? lds_s1 : (j == 2 ? lds_s2 : lds_s3)); };
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
+    const uint32_t wave_m = wave >> 2, wave_n = wave & 3u;
+
+    // XCD-aware mapping: see mfma_prefilter_kernel
+    const uint32_t total = gridDim.x;
+    const uint32_t id = blockIdx.x, xcd = id & 7u;
+    uint32_t strip, qtile;
+    if ((n_qtiles & 7u) == 0u) {
+        const uint32_t qpx = n_qtiles >> 3, within = id >> 3;
+        strip = within / qpx;
+        qtile = xcd * qpx + within % qpx;
+    } else {
+        const uint32_t q8 = total >> 3, r8 = total & 7u;
+        const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
+        strip = t / n_qtiles;
+        qtile = t % n_qtiles;
+    }
+    const uint32_t tile0 = strip * strip_tiles;
+    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
+    const uint32_t KT = KS / KU;
+    const uint32_t n_it = ntiles * KT;
+
+    // waves 0-3 stage the A (row) units, waves 4-7 the B (query) units: G pieces (1 KiB each) per wave
+    // and stage, as buffer_load_dwordx4 ... lds: the resource (SGPRs) points at the tile's first unit,
+    // the piece offset travels in an SGPR and the only VGPR operand is the constant lane * 16 -- no
+    // per-piece 64-bit vector address arithmetic.  Pieces are issued two per 8-MFMA group (see kstep)
+    // instead of as a burst behind the barrier.
+    const bool a_wave = wave < 4u;
+    const uint32_t lane16 = lane * 16u;
+    auto stage_rsrc = [&](uint32_t it) -> __amdgpu_buffer_rsrc_t {
+        const uint32_t tile = tile0 + it / KT;
+        const uint4 *base = a_wave ? A + (size_t)tile * 8u * KS * 64u : B + (size_t)qtile * 8u * KS * 64u;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00020000);
+    };
+    auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t kt, uint4 *dst, uint32_t u) {
+        const uint32_t unit = (wave & 3u) * G + u; // 0 .. 8 KU - 1, wave-uniform
+        const uint32_t grp = unit / KU, ks = unit % KU;
+        const uint32_t soff = ((grp * KS) + kt * KU + ks) * 1024u;
+        // LDS destination laundered: see glds16_untracked
+        uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(dst + ((a_wave ? 0u : A_UNITS) + unit) * 64u);
+        asm volatile("" : "+s"(a));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
+                                                 (int)lane16, (int)soff, 0, 0);
+    };
+    auto stage = [&](uint32_t it, uint4 *dst) {
+        const __amdgpu_buffer_rsrc_t rsrc = stage_rsrc(it);
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u)
+            stage_piece(rsrc, it % KT, dst, u);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[mi][ni][r] = 0.0f;
+    const float ninf = __uint_as_float(0xff800000u);
+    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
+
+    auto kstep = [&](auto jc, uint32_t it) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int JW = (J + NSTAGE - 1) % NSTAGE;
+        const uint4 *rd = slot(J);
+        // Every K-step issues exactly one stage (past the end: a redundant copy of the last one into
+        // the free slot), so NSTAGE-2 younger stages are always in flight here and the count is a
+        // constant.  It also keeps hipcc's own (path-insensitive) LDS-DMA bookkeeping off vmcnt(0):
+        // with conditional stages it must assume none was issued and drains the ring once per
+        // unrolled round.
+        if (G * (NSTAGE - 2) == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (G * (NSTAGE - 2) == 8)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory"); // no fragment read may be hoisted above the barrier
+        const uint32_t it_n = min(it + (uint32_t)(NSTAGE - 1), n_it - 1u);
+        const __amdgpu_buffer_rsrc_t rsrc_n = stage_rsrc(it_n);
+        const uint32_t kt_n = it_n % KT;
+        uint4 *wr = slot(JW);
+#pragma unroll
+        for (uint32_t ks = 0; ks < (uint32_t)KU; ++ks) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (uint32_t mi = 0; mi < 4; ++mi)
+                a[mi] = as_bf16x8(rd[((wave_m * 4u + mi) * KU + ks) * 64u + lane]);
+#pragma unroll
+            for (uint32_t ni = 0; ni < 2; ++ni)
+                b[ni] = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane]);
+            stage_piece(rsrc_n, kt_n, wr, 2u * ks);
+            stage_piece(rsrc_n, kt_n, wr, 2u * ks + 1u);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (it % KT == KT - 1u) {
+            // tile finished: fold its 128 scores per lane into the running top-3 of each query column.
+            // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+            const uint32_t ts = it / KT;
+            const uint32_t tile_row0 = (tile0 + ts) * TROWS;
+            const bool ragged = tile_row0 + TROWS > n_rows;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t idx = (ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r;
+                        float sp = __uint_as_float((__float_as_uint(acc[mi][ni][r]) & ~kIdxMask) | idx);
+                        if (ragged) {
+                            const uint32_t row = tile_row0 + wave_m * 128u + (uint32_t)mi * 32u + ((uint32_t)r & 3u) +
+                                                 8u * ((uint32_t)r >> 2) + 4u * (lane >> 5);
+                            if (row >= n_rows)
+                                sp = ninf;
+                        }
+                        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
+                        m1[ni] = fmaxf(m1[ni], sp);
+                        acc[mi][ni][r] = 0.0f;
+                    }
+        }
+    };
+
+    stage(0, lds_s0); // n_it >= 2 (KS >= 4, KU <= 4 ... KT >= 1; ntiles >= 1): clamp below keeps it general
+    if (NSTAGE > 2)
+        stage(min(1u, n_it - 1u), lds_s1);
+    if (NSTAGE > 3)
+        stage(min(2u, n_it - 1u), lds_s2);
+    // n_it % NSTAGE == 0 (the host pads K so that KT is a multiple of NSTAGE): a straight-line round
+    for (uint32_t it = 0; it < n_it; it += NSTAGE) {
+        kstep(std::integral_constant<int, 0>{}, it);
+        kstep(std::integral_constant<int, 1>{}, it + 1);
+        if (NSTAGE > 2)
+            kstep(std::integral_constant<int, (NSTAGE > 2 ? 2 : 0)>{}, it + 2);
+        if (NSTAGE > 3)
+            kstep(std::integral_constant<int, (NSTAGE > 3 ? 3 : 0)>{}, it + 3);
+    }
+
+    // the redundant tail stages are still in flight: they must land before this workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
+        if (q < nq) {
+            cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
+            cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
+            cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+        }
+    }
+}
+
 // ---- select: kp best approximate scores of one query ------------------------------------------
 // composite = key(-score) << 32 | list ; smaller = better.  One workgroup per query.
 template <typename TopK, int WAVES>
@@ -356,14 +557,19 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
 }
 
 // ---- exact re-score + safety check ----------------------------------------------------------------
-__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles, uint32_t wm)
+// wave_rows = rows per wave tile: 64 (mi: 1 bit) for mfma_prefilter_kernel, 128 (mi: 2 bits) for
+// mfma_prefilter256_kernel
+__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles, uint32_t wm,
+                                             uint32_t wave_rows)
 {
     const uint32_t list = (uint32_t)comp;
     score = -key_dist((uint32_t)(comp >> 32));
     const uint32_t idx = __float_as_uint(score) & kIdxMask;
-    const uint32_t ts = idx >> 5, mi = (idx >> 4) & 1u, r = idx & 15u;
+    const uint32_t mi_bits = wave_rows == 128u ? 2u : 1u;
+    const uint32_t ts = idx >> (4u + mi_bits), mi = (idx >> 4) & ((1u << mi_bits) - 1u), r = idx & 15u;
     const uint32_t strip = list / (2u * wm), wave_m = (list % (2u * wm)) >> 1, half = list & 1u;
-    return (strip * strip_tiles + ts) * (64u * wm) + wave_m * 64u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+    return (strip * strip_tiles + ts) * (wave_rows * wm) + wave_m * wave_rows + mi * 32u + (r & 3u) + 8u * (r >> 2) +
+           4u * half;
 }
 
 template <int DTYPE, typename TopK>
@@ -372,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, float eps, uint64_t row_base, uint64_t id_base,
-    uint32_t strip_tiles, uint32_t wm)
+    uint32_t strip_tiles, uint32_t wm, uint32_t wave_rows)
 {
     constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
     extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)]
@@ -404,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     float score = 0.0f;
     uint32_t row = 0;
     if (valid)
-        row = cand_row(comp_a, score, strip_tiles, wm);
+        row = cand_row(comp_a, score, strip_tiles, wm, wave_rows);
     const bool in_range = valid && row < n_rows;
     if (wave * 64u < kp) { // wave-uniform: this wave has candidates
         const uint32_t r = in_range ? row : 0u;
@@ -535,9 +741,15 @@ hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t 
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, hipStream_t s)
 {
-    const uint32_t n_qtiles = (nq + kTileQueries - 1) / kTileQueries;
+    const uint32_t n_qtiles = (nq + g.tile_queries - 1) / g.tile_queries;
     const dim3 grid(g.n_strips * n_qtiles);
-    if (g.wm == 4)
+    if (g.variant == 0)
+        hipLaunchKernelGGL((mfma_prefilter256_kernel<2, 4>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror,
+                           cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+    else if (g.variant == 1)
+        hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror,
+                           cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+    else if (g.wm == 4)
         hipLaunchKernelGGL((mfma_prefilter_kernel<4, 3>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror, cand,
                            n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
     else
@@ -568,20 +780,27 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     if (dtype == VFSX_I8)
         hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_I8, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
-                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm);
+                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows);
     else
         hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_F32, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
-                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm);
+                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows);
     return hipGetLastError();
 }
 
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t wm)
+// variant: 0 = 256 x 256 tile, BK 32, 4-slot ring (default); 1 = 256 x 256, BK 64, 2 slots;
+//          2 = 256 x 128 (wm 4, 3 slots); 3 = 128 x 128 (wm 2, 2 slots)
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t variant)
 {
     MfmaGeometry g;
-    g.wm = wm == 2 ? 2u : 4u; // waves along M: tile = 64*wm rows x 128 queries
-    const uint32_t tile_rows = 64u * g.wm;
-    g.k_pad = (dim + 63u) / 64u * 64u;
+    g.variant = variant > 3u ? 0u : variant;
+    g.wave_rows = g.variant <= 1u ? 128u : 64u;
+    g.wm = g.variant == 2u ? 4u : 2u; // waves along M
+    g.tile_queries = g.variant <= 1u ? 256u : 128u;
+    const uint32_t tile_rows = g.wave_rows * g.wm;
+    // the 256 x 256 kernels run whole ring rounds only: K-steps per tile % ring depth == 0 <=> K % 128 == 0
+    const uint32_t k_mult = g.variant <= 1u ? 128u : 64u;
+    g.k_pad = (dim + k_mult - 1u) / k_mult * k_mult;
     g.KS = g.k_pad / 16u;
     g.n_rowtiles = (n_rows + tile_rows - 1) / tile_rows;
     // aim for >= ~4096 candidate lists per query so that three rows above the safety margin rarely share
