@@ -109,3 +109,20 @@ def test_mfma_bad_queries_and_append_after_enable(oracle):
         oi, od, _ = oracle.topk_scan(rows, queries[qi], 1, 10)
         assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
     c.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_mfma_every_prefilter_kernel(oracle, monkeypatch, variant):
+    """The four prefilter kernels (256x256 tile with a 4-slot / 2-slot ring, 256x128, 128x128;
+    VFSX_MFMA_VARIANT, read when the corpus is created) all feed the same exact re-score."""
+    import vfs_amd
+    monkeypatch.setenv("VFSX_MFMA_VARIANT", str(variant))
+    rng = np.random.default_rng(900 + variant)
+    n, d = 70001, 200  # ragged last tile; K padded to 256
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (300, d)).astype(np.float32)  # ragged query tile as well
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    fb = _compare(c, queries, 10, oracle, rows)
+    assert fb <= 30
+    c.close()

@@ -163,7 +163,7 @@ struct vfsx_corpus {
     int *d_mirror_bad = nullptr; // device flag: a row with zero / non-finite norm exists
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 64;
-    uint32_t mfma_wm = 0; // prefilter kernel variant (vfsx::mfma_geometry): 0 = 256 x 256 tile, 4-slot ring
+    uint32_t mfma_wm = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
     DeviceBuf<float> cand;
@@ -665,7 +665,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
-        c->mfma_wm = (uint32_t)std::min<uint64_t>(3, env_u64("VFSX_MFMA_VARIANT", 0));
+        c->mfma_wm = (uint32_t)std::min<uint64_t>(3, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)

@@ -439,8 +439,14 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 #pragma unroll
             for (uint32_t ni = 0; ni < 2; ++ni)
                 b[ni] = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane]);
-            stage_piece(rsrc_n, kt_n, wr, 2u * ks);
-            stage_piece(rsrc_n, kt_n, wr, 2u * ks + 1u);
+            // next stage's pieces: spread over the K-step when the ring gives them NSTAGE-1 >= 2 K-steps
+            // to land, front-loaded (first half of the K-step) when the very next barrier needs them
+            constexpr uint32_t PPK = NSTAGE > 2 ? 2u : 4u;
+            if (ks * PPK < G) {
+#pragma unroll
+                for (uint32_t u = 0; u < PPK; ++u)
+                    stage_piece(rsrc_n, kt_n, wr, ks * PPK + u);
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
