@@ -140,3 +140,82 @@ def test_log_ingest_large_dense_records(tmp_path, oracle):
         e.load_log(str(p))  # Dense records cannot enter a quantized corpus
     for x in (c, d, e):
         x.close()
+
+
+def _mk_server(tmp_path):
+    from vfs_amd import server
+    s = server.VfsServer(port=0, state_dir=str(tmp_path / "state"))
+    threading.Thread(target=s.serve_forever, daemon=True).start()
+    return s, s.server_address[1]
+
+
+def _stop(s):
+    s.shutdown()
+    s.server_close()
+    if s.app.state is not None:
+        s.app.state.corpus.close()
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_flush_snapshot_restart_restore(tmp_path, oracle, quantize):
+    """F3/F4: registered vectors reach data/vectors.dat in the reference's record format (auto flush
+    every 10, storage_manager.rs:12,310-312), /snapshot writes the reference's bincode VFSState, and
+    a restarted server serves the same data directory: same /search answer, ids continue."""
+    from tests.test_log_cpu import _parse_records
+    from vfs_amd import vfslog
+    rng = np.random.default_rng(11)
+    rows = rng.uniform(-1, 1, (23, 8)).astype(np.float32)
+    q = rng.uniform(-1, 1, 8).astype(np.float32)
+    sbody = {"values": [float(x) for x in q], "top_k": 5, "ef_search": 7, "distance_method": "cosine"}
+    data = tmp_path / "data" / "vectors.dat"
+
+    a, port = _mk_server(tmp_path)
+    try:
+        assert _req(port, "POST", "/init", {"vector_dimension": 8, "storage_name": "shop", "truncate_data": True,
+                                            "quantize": quantize})[0] == 200
+        for i, r in enumerate(rows):
+            assert _req(port, "POST", "/vectors", {"values": [float(x) for x in r], "name": f"v{i}",
+                                                   "tags": ["t", str(i)]})[0] == 201
+        assert len(_parse_records(data.read_bytes())) == 20           # two automatic flushes, 3 still pending
+        before = _req(port, "POST", "/search", sbody)
+        assert before[0] == 200
+        assert _req(port, "POST", "/snapshot")[0] == 200
+    finally:
+        _stop(a)
+
+    recs = _parse_records(data.read_bytes())
+    assert [r[0] for r in recs] == list(range(1, 24))
+    if quantize:
+        assert all(r[5] == 127.0 for r in recs)
+        assert np.array_equal(np.array([r[1] for r in recs], np.int8), oracle.quantize(rows, 127.0))
+        assert recs[4][2] == "v4_quantized" and recs[4][3] == ["t", "4", "quantized"]
+    else:
+        assert np.array_equal(np.array([r[1] for r in recs], np.float32).view(np.uint32), rows.view(np.uint32))
+        assert recs[4][2] == "v4" and recs[4][3] == ["t", "4"]
+    st = vfslog.decode_state((tmp_path / "state" / "vfs_state.bin").read_bytes())
+    assert st["name"] == "shop" and st["next_id"] == 24 and st["quantize"] == quantize
+    offs, pos = [], 0
+    for r in recs:  # index_map = id -> offset of its record
+        offs.append(pos)
+        pos += len(vfslog.encode_record(r[0], r[1], r[2], r[3], r[4], scale=r[5]))
+    assert st["index_map"] == {i + 1: o for i, o in enumerate(offs)}
+
+    b, port = _mk_server(tmp_path)
+    try:
+        assert _req(port, "POST", "/init", {"vector_dimension": 8, "truncate_data": False, "quantize": quantize})[0] == 200
+        after = _req(port, "POST", "/search", sbody)
+        strip = lambda body: [(r["id"], r["distance"], r["vector"]) for r in json.loads(body)["results"]]
+        assert after[0] == 200 and strip(after[1]) == strip(before[1])
+        assert _req(port, "POST", "/restore") == (200, '{"status":"State loaded successfully"}')
+        assert b.app.state.name == "shop"
+        st, body = _req(port, "POST", "/vectors", {"values": [0.0] * 8, "name": "late", "tags": []})
+        assert (st, body) == (201, '{"id":24,"status":"success"}')
+    finally:
+        _stop(b)
+
+
+def test_restore_without_snapshot_is_500(srv):
+    s, port = srv
+    _req(port, "POST", "/init", {"vector_dimension": 4, "truncate_data": True, "quantize": False})
+    st, body = _req(port, "POST", "/restore")
+    assert st == 500 and body.startswith('{"error":"Failed to load state: I/O error:')

@@ -112,8 +112,12 @@ def err_body(msg: str) -> str:
 
 # ---- the state behind the mutex (ServerState, tcp.rs:60-63) --------------------------------------
 
+FLUSH_THRESHOLD = 10  # storage_manager.rs:12
+
+
 class ServerState:
-    def __init__(self, dim: int, quantize: bool, name: str, device: int = 0, state_dir: str = "state"):
+    def __init__(self, dim: int, quantize: bool, name: str, device: int = 0, state_dir: str = "state",
+                 data_dir: str = "data"):
         import vfs_amd
         self.vector_dimension = dim
         self.quantize = quantize
@@ -122,9 +126,14 @@ class ServerState:
         self.next_id = 1                      # storage_manager.rs:76
         self.row_of = {}                      # id -> local row
         self.meta = {}                        # id -> (name, tags) as the store holds them
-        self.state_path = os.path.join(state_dir, "vfs_state.json")
+        self.memtable = []                    # [(id, created_at)] registered, not yet in the log
+        self.index_map = {}                   # id -> log offset (storage_manager.rs:61)
+        self.current_offset = 0
+        self.state_path = os.path.join(state_dir, "vfs_state.bin")   # storage_manager.rs:14
+        self.data_path = os.path.join(data_dir, "vectors.dat")       # storage_manager.rs:13
 
     def register(self, values, name: str, tags) -> int:
+        from . import vfslog
         vid = self.next_id
         self.next_id += 1
         row = len(self.corpus)
@@ -134,7 +143,31 @@ class ServerState:
             self.meta[vid] = (name + "_quantized", list(tags) + ["quantized"])
         else:
             self.meta[vid] = (name, list(tags))
+        self.memtable.append((vid, vfslog.utc_now_rfc3339()))
+        if len(self.memtable) >= FLUSH_THRESHOLD:  # storage_manager.rs:310-312
+            self.flush()
         return vid
+
+    def flush(self) -> None:
+        """flush_memtable_to_disk (storage_manager.rs:139-157): append the pending vectors to the log in
+        the reference's record format -- the stored form, i.e. the int8 values read back from HBM for a
+        quantizing store -- and index them by offset."""
+        from . import vfslog
+        if not self.memtable:
+            return
+        rows = [self.row_of[vid] for vid, _ in self.memtable]
+        values = self.corpus.get_rows_raw(rows)
+        recs = []
+        for (vid, created), v in zip(self.memtable, values):
+            name, tags = self.meta[vid]
+            if self.quantize:  # quantize() stamps a fresh created_at (vector.rs:122)
+                recs.append(vfslog.encode_record(vid, v, name, tags, vfslog.utc_now_rfc3339(), scale=127.0))
+            else:
+                recs.append(vfslog.encode_record(vid, v, name, tags, created))
+        offsets = vfslog.append_records(self.data_path, recs)
+        for (vid, _), off in zip(self.memtable, offsets):
+            self.index_map[vid] = off
+        self.memtable = []
 
     def load_log(self, path: str) -> int:
         row0 = len(self.corpus)
@@ -161,11 +194,14 @@ class ServerState:
 class App:
     """Routes of tcp.rs:107-150 on one ServerState behind one lock."""
 
-    def __init__(self, device: int = 0, state_dir: str = "state"):
+    def __init__(self, device: int = 0, state_dir: str = "state", data_dir: Optional[str] = None):
         self.lock = threading.Lock()
         self.state: Optional[ServerState] = None
         self.device = device
         self.state_dir = state_dir
+        # the reference keeps data/ and state/ side by side under its working directory
+        self.data_dir = data_dir if data_dir is not None else os.path.join(
+            os.path.dirname(os.path.abspath(state_dir)), "data")
 
     # -- helpers -------------------------------------------------------------------------------
     @staticmethod
@@ -205,6 +241,11 @@ class App:
         if method == "POST" and path == "/flush":
             if self.state is None:
                 return 400, err_body("VFSManager is not initialized")
+            try:
+                self.state.flush()
+            except OSError as e:  # VFSError::MemtableError (tcp.rs:221-228)
+                return 500, jobj([("error", jstr(f"Memtable error: I/O error: {e}")),
+                                  ("error_type", jstr("memtable_error")), ("status", jstr("error"))])
             return 200, jobj([("status", jstr("success")), ("message", jstr("Memtable flushed to disk"))])
         if method == "POST" and path == "/snapshot":
             return self.snapshot()
@@ -241,8 +282,30 @@ class App:
         if self.state is not None:
             return 400, err_body("VFSManager is already initialized")
         name = req.get("storage_name") or "default_vfs"
-        self.state = ServerState(req["vector_dimension"], req["quantize"], name, self.device, self.state_dir)
+        st = ServerState(req["vector_dimension"], req["quantize"], name, self.device, self.state_dir, self.data_dir)
+        if req["truncate_data"]:  # reset_state(truncate_data_file), storage_manager.rs:85-98
+            os.makedirs(os.path.dirname(st.data_path) or ".", exist_ok=True)
+            open(st.data_path, "wb").close()
+        else:
+            # the reference's scan reads the log from offset 0 (rank.rs:139-156), so an existing data file
+            # is part of every search: stream it into HBM now.  A file this store cannot hold (other
+            # dimension or storage type) is left alone, as the reference would only fail at search time.
+            self._load_existing_log(st)
+        self.state = st
         return 200, jobj([("status", jstr("initialized"))])
+
+    @staticmethod
+    def _load_existing_log(st: ServerState) -> int:
+        from . import vfslog, _lib
+        if len(st.corpus) or not os.path.exists(st.data_path) or os.path.getsize(st.data_path) == 0:
+            return 0
+        try:
+            info = vfslog.inspect(st.data_path)
+            if info["records"] == 0 or info["dim"] != st.vector_dimension or info["quantized"] != st.quantize:
+                return 0
+            return st.load_log(st.data_path)
+        except _lib.VfsxError:
+            return 0
 
     def register_vector(self, req) -> Tuple[int, str]:  # tcp.rs:301-363
         st = self.state
@@ -295,30 +358,50 @@ class App:
             results.append(jobj([("id", str(vid)), ("distance", fmt_f32_widened(dist)), ("vector", vec)]))
         return 200, jobj([("results", "[" + ",".join(results) + "]"), ("query_time_ms", fmt_f32_widened(ms))])
 
-    def snapshot(self) -> Tuple[int, str]:  # tcp.rs:182-195 (state only; the vectors live in HBM / the log)
+    def snapshot(self) -> Tuple[int, str]:  # tcp.rs:182-195, storage_manager.rs:367-410
+        """Writes state/vfs_state.bin in the reference's bincode layout and flushes the memtable.
+        Deviation: the reference encodes the state BEFORE the flush, so its snapshot's index_map misses
+        the vectors that flush writes; here the flush comes first and the snapshot indexes everything."""
+        from . import vfslog
         st = self.state
         if st is None:
             return 400, err_body("VFS Manager not initialized")
         try:
+            st.flush()
             os.makedirs(os.path.dirname(st.state_path) or ".", exist_ok=True)
-            with open(st.state_path, "w") as f:
-                json.dump({"name": st.name, "next_id": st.next_id, "quantize": st.quantize,
-                           "vector_dimension": st.vector_dimension, "rows": len(st.corpus)}, f)
+            with open(st.state_path, "wb") as f:
+                f.write(vfslog.encode_state(st.name, st.next_id, st.current_offset, st.index_map, st.quantize))
         except OSError as e:
             return 500, err_body(f"Failed to save state: I/O error: {e}")
         return 200, jobj([("status", jstr("State saved successfully"))])
 
-    def restore(self) -> Tuple[int, str]:  # tcp.rs:198-211
+    def restore(self) -> Tuple[int, str]:  # tcp.rs:198-211, storage_manager.rs:412-427
+        """Loads the VFSState; the vectors themselves are re-streamed from the log into HBM when this
+        store is still empty (the reference keeps them on disk and re-reads the log on every search)."""
+        from . import vfslog
         st = self.state
         if st is None:
             return 400, err_body("VFS Manager not initialized")
         try:
-            with open(st.state_path) as f:
-                saved = json.load(f)
-            st.name = saved["name"]
-            st.next_id = max(st.next_id, int(saved["next_id"]))
-        except (OSError, ValueError, KeyError) as e:
+            with open(st.state_path, "rb") as f:
+                saved = vfslog.decode_state(f.read())
+        except OSError as e:
             return 500, err_body(f"Failed to load state: I/O error: {e}")
+        except ValueError as e:
+            return 500, err_body(f"Failed to load state: Serialization error: {e}")
+        if saved["quantize"] != st.quantize and len(st.corpus):
+            return 500, err_body("Failed to load state: Internal error: snapshot storage type differs from the "
+                                 "resident corpus")
+        if saved["quantize"] != st.quantize:  # empty store: adopt the snapshot's storage type
+            import vfs_amd
+            st.corpus.close()
+            st.quantize = saved["quantize"]
+            st.corpus = vfs_amd.Corpus(st.vector_dimension, quantize=st.quantize, device=self.device)
+        st.name = saved["name"]
+        st.index_map = dict(saved["index_map"])
+        st.current_offset = saved["current_offset"]
+        self._load_existing_log(st)
+        st.next_id = max(st.next_id, int(saved["next_id"]))
         return 200, jobj([("status", jstr("State loaded successfully"))])
 
 
