@@ -168,3 +168,22 @@ def test_multi_query_passes_bit_exact(oracle, quantize, nq):
                 assert cnt[qi] == k and (ids[qi] == oi).all(), (metric, k, qi)
                 assert (bits(dist[qi]) == bits(od)).all(), (metric, k, qi)
     c.close()
+
+
+def test_large_k_batch_splits_into_several_launches(oracle):
+    """k = 700 over >= 4096 row-blocks makes one query's list workspace 5.7 MB, so a 60-query batch
+    exceeds the 256 MiB workspace and is scanned in several launches: results must not depend on it."""
+    import vfs_amd
+    n, d, k, nq = 270_000, 4, 700, 60
+    rows = oracle.synth_f32(41, 0, n, d)
+    queries = oracle.synth_f32(42, 0, nq, d)
+    c = vfs_amd.Corpus(d, capacity_rows=n)
+    c.append(rows)
+    for metric in (0, 1):
+        ids, dist, cnt = c.search_batch(queries, k, metric)
+        assert (cnt == k).all()
+        for qi in (0, 31, 45, 46, 59):  # both sides of the launch boundary
+            oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k)
+            assert (ids[qi] == oi).all()
+            assert (dist[qi].view(np.uint32) == od.view(np.uint32)).all()
+    c.close()
