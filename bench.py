@@ -38,6 +38,8 @@ WORKLOADS = {
                                        "arithmetic; SURVEY 8a A6(ii)), exact top-10"),
     "c1": (100_000, 128, False, 2, "C1 100kx128 f32 SimdEuclidean exact top-10"),
     "c5": (12_500_000, 768, False, 0, "C5 shard 12.5Mx768 f32 Euclidean (100Mx768 over 8 GPUs)"),
+    "c4e": (10_000_000, 1024, False, 0, "4096-query batch x 10Mx1024 Euclidean as Q.X^T on bf16 MFMA + per-row upper-bound "
+                                         "epilogue + fused top-k, exact f32 re-score (extension of C4 to the Euclidean metric)"),
     "c4": (10_000_000, 1024, False, 1, "C4 4096-query batch x 10Mx1024 Cosine as Q.X^T on bf16 MFMA + fused top-k, "
                                         "exact f32 re-score"),
 }
@@ -100,7 +102,7 @@ def main() -> int:
 
     dbg("process group up")
     rows, dim, quantize, metric, label = WORKLOADS[args.workload]
-    mfma = args.workload == "c4"
+    mfma = args.workload in ("c4", "c4e")
     if mfma:
         args.mode = "batch"
         if args.queries_per_step == 16:

@@ -95,25 +95,27 @@ def test_c3_10m_x128_int8_euclidean(oracle):
 def test_c4_10m_x1024_mfma_batch_equals_exact_scan(oracle):
     """BASELINE config 4 at full size: a 4096-query Cosine batch through the MFMA path must
     equal the exact scan (itself checked against the oracle above) on sampled queries, and a
-    sampled row's exact distance must equal the oracle's on the regenerated row."""
+    sampled row's exact distance must equal the oracle's on the regenerated row.  The same for
+    the Euclidean extension of the batch path, on the same resident corpus."""
     import vfs_amd
     n, d, nq, k = 10_000_000, 1024, 4096, 10
     c = vfs_amd.Corpus(d, capacity_rows=n)
     c.fill_synthetic(SEED_C, n)
     queries = oracle.synth_f32(SEED_Q, 0, nq, d)
-    c.enable_mfma(True)
-    c.mfma_stats(reset=True)
-    ids_m, dist_m, cnt_m = c.search_batch(queries, k, 1)
-    mq, fb = c.mfma_stats()
-    assert mq == nq and fb < nq // 10
-    c.enable_mfma(False)
-    sample = [0, 1, 777, 2048, 4095, 3, 4, 5]
-    ids_e, dist_e, _ = c.search_batch(queries[sample], k, 1)
-    assert (ids_m[sample] == ids_e).all()
-    assert (bits(dist_m[sample]) == bits(dist_e)).all()
-    assert (cnt_m == k).all() and (np.diff(dist_m, axis=1) >= 0).all()
-    # the winner of query 0: regenerate that row on the host and check the oracle's distance
-    row = int(ids_m[0, 0]) - 1
-    x = oracle.synth_f32(SEED_C, row, 1, d)
-    assert bits(oracle.all_distances(x, queries[0], 1))[0] == bits(dist_m[0, :1])[0]
+    for metric in (1, 0):
+        c.enable_mfma(True)
+        c.mfma_stats(reset=True)
+        ids_m, dist_m, cnt_m = c.search_batch(queries, k, metric)
+        mq, fb = c.mfma_stats()
+        assert mq == nq and fb < nq // 10
+        c.enable_mfma(False)
+        sample = [0, 1, 777, 2048, 4095, 3, 4, 5]
+        ids_e, dist_e, _ = c.search_batch(queries[sample], k, metric)
+        assert (ids_m[sample] == ids_e).all()
+        assert (bits(dist_m[sample]) == bits(dist_e)).all()
+        assert (cnt_m == k).all() and (np.diff(dist_m, axis=1) >= 0).all()
+        # the winner of query 0: regenerate that row on the host and check the oracle's distance
+        row = int(ids_m[0, 0]) - 1
+        x = oracle.synth_f32(SEED_C, row, 1, d)
+        assert bits(oracle.all_distances(x, queries[0], metric))[0] == bits(dist_m[0, :1])[0]
     c.close()

@@ -12,21 +12,21 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def _compare(c, queries, k, oracle=None, rows=None):
+def _compare(c, queries, k, oracle=None, rows=None, metric=1):
     """MFMA batch result vs the exact scan of the same corpus (and vs the oracle on a sample)."""
     c.enable_mfma(True)
     c.mfma_stats(reset=True)
-    ids_m, dist_m, cnt_m = c.search_batch(queries, k, 1)
+    ids_m, dist_m, cnt_m = c.search_batch(queries, k, metric)
     nq_m, fb = c.mfma_stats()
     assert nq_m == len(queries), "the batch did not take the MFMA path"
     c.enable_mfma(False)
-    ids_e, dist_e, cnt_e = c.search_batch(queries, k, 1)
+    ids_e, dist_e, cnt_e = c.search_batch(queries, k, metric)
     assert (cnt_m == cnt_e).all()
     assert (ids_m == ids_e).all()
     assert (bits(dist_m) == bits(dist_e)).all()
     if oracle is not None:
         for qi in range(0, len(queries), max(1, len(queries) // 5)):
-            oi, od, _ = oracle.topk_scan(rows, queries[qi], 1, k)
+            oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k)
             assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
     return fb
 
@@ -125,4 +125,74 @@ def test_mfma_every_prefilter_kernel(oracle, monkeypatch, variant):
     c.append(rows)
     fb = _compare(c, queries, 10, oracle, rows)
     assert fb <= 30
+    c.close()
+
+
+# ---- Euclidean batches: same contraction, upper-bound epilogue  key = 2ab(s~ + eps) - b^2(1 - gamma) ----
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("d,n,k", [(128, 40000, 10), (100, 33333, 5), (768, 20000, 10)])
+def test_mfma_euclidean_batch_equals_exact_f32(oracle, d, n, k, metric):
+    import vfs_amd
+    rng = np.random.default_rng(d + n + metric)
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (200, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    fb = _compare(c, queries, k, oracle, rows, metric=metric)
+    assert fb <= 100
+    c.close()
+
+
+def test_mfma_euclidean_wildly_varying_norms(oracle):
+    """Row norms over three decades and queries of different lengths: the epilogue's bound is per row
+    (b) and per query (a); the nearest rows are the short ones, not the best-aligned ones."""
+    import vfs_amd
+    rng = np.random.default_rng(21)
+    n, d = 60000, 96
+    rows = (rng.uniform(-1, 1, (n, d)) * np.exp(rng.uniform(np.log(0.01), np.log(10.0), (n, 1)))).astype(np.float32)
+    queries = (rng.uniform(-1, 1, (160, d)) * np.exp(rng.uniform(np.log(0.05), np.log(5.0), (160, 1)))).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    _compare(c, queries, 10, oracle, rows, metric=0)
+    c.close()
+
+
+def test_mfma_euclidean_int8_and_clustered(oracle):
+    import vfs_amd
+    rng = np.random.default_rng(22)
+    n, d = 50000, 96
+    rows = rng.integers(-128, 128, (n, d), dtype=np.int8)
+    queries = rng.uniform(-1, 1, (130, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=True)
+    c.append(rows)
+    _compare(c, queries, 10, oracle, rows, metric=0)
+    c.close()
+    # near-duplicates next to each other: the check must flag, the exact scan must answer
+    n, d = 30000, 64
+    centers = rng.uniform(-1, 1, (30, d)).astype(np.float32)
+    rows = (np.repeat(centers, n // 30, axis=0) + rng.normal(0, 1e-3, (n, d))).astype(np.float32)
+    queries = (centers[rng.integers(0, 30, 128)] + rng.normal(0, 1e-3, (128, d))).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    fb = _compare(c, queries, 10, oracle, rows, metric=0)
+    assert fb > 0
+    c.close()
+
+
+def test_mfma_euclidean_needs_the_256_kernels(monkeypatch, oracle):
+    """The older prefilter kernels have no Euclidean epilogue: such batches use the exact scan."""
+    import vfs_amd
+    monkeypatch.setenv("VFSX_MFMA_VARIANT", "2")
+    rng = np.random.default_rng(23)
+    rows = rng.uniform(-1, 1, (20000, 64)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (128, 64)).astype(np.float32)
+    c = vfs_amd.Corpus(64)
+    c.append(rows)
+    c.enable_mfma(True)
+    c.mfma_stats(reset=True)
+    ids, dist, _ = c.search_batch(queries, 10, 0)
+    assert c.mfma_stats()[0] == 0
+    oi, od, _ = oracle.topk_scan(rows, queries[5], 0, 10)
+    assert (ids[5] == oi).all() and (bits(dist[5]) == bits(od)).all()
     c.close()

@@ -161,6 +161,9 @@ struct vfsx_corpus {
     uint64_t mirror_rows = 0; // rows the mirror currently covers (0 = stale / absent)
     size_t mirror_bytes = 0;
     int *d_mirror_bad = nullptr; // device flag: a row with zero / non-finite norm exists
+    float *d_rn2 = nullptr;      // [mirror rows padded] float2 (b, b^2 (1 - gamma)) for Euclidean batches
+    size_t rn2_rows = 0;
+    DeviceBuf<float> q_norm;
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 64;
     uint32_t mfma_wm = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
@@ -450,10 +453,18 @@ void free_mirror(vfsx_corpus *c)
 {
     if (c->d_mirror)
         (void)hipFree(c->d_mirror);
+    if (c->d_rn2)
+        (void)hipFree(c->d_rn2);
+    c->d_rn2 = nullptr;
+    c->rn2_rows = 0;
     c->d_mirror = nullptr;
     c->mirror_rows = 0;
     c->mirror_bytes = 0;
 }
+
+// relative allowance for the f32 errors in the Euclidean batch check (vfsx_mfma.hip): the reference's
+// sequential sums of d terms, the row norm b vs ||x||, the query norm a vs ||q||, and the epilogue's roundings
+float mfma_gamma(uint32_t k_pad) { return ((float)k_pad + 32.0f) * 0x1p-23f; }
 
 // (re)build the bf16 mirror when rows were appended since it was made
 void ensure_mirror(vfsx_corpus *c, hipStream_t s)
@@ -472,6 +483,18 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
     HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror, (uint32_t)c->n_rows,
                                        c->dim, c->d_chunks, g.KS, (uint32_t)(g.mirror_bytes / ((size_t)g.k_pad * 2u * 32u)),
                                        c->d_mirror_bad, s));
+    if (g.variant <= 1u) { // Euclidean batches (256 x 256 kernels only)
+        const size_t n_pad = (size_t)g.n_rowtiles * g.wave_rows * g.wm;
+        if (n_pad > c->rn2_rows) {
+            if (c->d_rn2)
+                (void)hipFree(c->d_rn2);
+            c->d_rn2 = nullptr;
+            HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
+            c->rn2_rows = n_pad;
+        }
+        HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad,
+                                                  mfma_gamma(g.k_pad), c->d_rn2, s));
+    }
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_bad, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -490,6 +513,8 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_wm);
     const uint32_t kp = k <= 8 ? 64u : (k <= 32 ? 128u : 256u);
     const float eps = vfsx::mfma_epsilon(g.k_pad);
+    const int euclid = is_cosine(metric) ? 0 : 1;
+    const float eps_e = eps - 0x1p-13f; // no index bits inside s~ on the Euclidean path (they go into the key)
 
     const uint32_t q_stride_pad = c->d_chunks * c->epc;
     const bool need_pad = (q_stride_pad != c->dim);
@@ -509,6 +534,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     c->sel.reserve((size_t)q_round * kp);
     c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
     c->q_bad.reserve(nq);
+    c->q_norm.reserve(nq);
     c->q_flags.reserve(nq);
     c->h_flags.assign(nq, 0);
 
@@ -517,10 +543,11 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         const uint32_t qn_pad = (qn + 255u) / 256u * 256u;
         HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * 2u, s));
         HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
-                                               c->q_bad.p + q0, s));
+                                               c->q_bad.p + q0, c->q_norm.p + q0, s));
         size_t slot = 0;
         prof_begin(c, s, slot);
-        HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, s));
+        HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
+                                              c->d_rn2, c->q_norm.p + q0, eps_e, s));
         prof_end(c, s, slot);
         HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, s));
         vfsx::MfmaRescoreArgs a{};
@@ -544,6 +571,9 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.strip_tiles = g.strip_tiles;
         a.wm = g.wm;
         a.wave_rows = g.wave_rows;
+        a.euclid = euclid;
+        a.q_norm = c->q_norm.p + q0;
+        a.gamma = mfma_gamma(g.k_pad);
         HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
     }
     HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -579,7 +609,9 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         return;
     if (!d_queries || !d_hits)
         fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
-    const bool mfma_ok = c->mfma_enabled && is_cosine(metric) && nq >= c->mfma_min_batch && k <= 64 &&
+    // Cosine on every prefilter kernel; Euclidean (the reference's metric or its Simd twin) on the 256 x 256 ones
+    const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && c->mfma_wm <= 1u);
+    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok) {
         use_device(c);
@@ -707,6 +739,7 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
         (void)hipFree(c->d_mirror_bad);
     c->q_mirror.release();
     c->q_bad.release();
+    c->q_norm.release();
     c->q_flags.release();
     c->cand.release();
     c->sel.release();

@@ -111,14 +111,21 @@ struct MfmaRescoreArgs {
     float eps;
     uint64_t row_base, id_base;
     uint32_t strip_tiles, wm, wave_rows;
+    int euclid;           // 0 = Cosine, 1 = Euclidean (see vfsx_mfma.hip)
+    const float *q_norm;  // [nq] the scalar each query mirror row was divided by
+    float gamma;          // relative f32 error allowance of the Euclidean check
 };
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
                               uint32_t n_rowgroups, int *bad_flag, hipStream_t s);
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                  int *q_bad, hipStream_t s);
+                                  int *q_bad, float *q_norm, hipStream_t s);
+// out[n_pad] float2 = (b, b^2 (1 - gamma)), zero beyond n_rows
+hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
+                                     hipStream_t s);
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
-                                 const MfmaGeometry &g, uint32_t nq, hipStream_t s);
+                                 const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
+                                 const float *q_norm, float eps_e, hipStream_t s);
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
                               hipStream_t s);
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);

@@ -6,7 +6,8 @@
 // The reference has no multi-query API (rank.rs:90 takes one &VFSVector); the batch is
 // defined as "A3 + A4 applied independently per query" (batch note), so
 // the observable result of this path must equal the single-query scan's bit for bit.
-// Pipeline (cosine only; Euclidean batches use the exact multi-query scan):
+// Pipeline (Cosine; the Euclidean variant differs only in the prefilter epilogue and the check, see
+// mfma_prefilter256_kernel MODE 1 and mfma_rescore_kernel):
 //
 //   mirror   X~ = bf16(x / ||x||) in MFMA fragment order          (built once per corpus)
 //   prep     Q~ = bf16(q / ||q||) in the same order               (per batch)
@@ -93,9 +94,25 @@ __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float
                                            h[6] | (h[7] << 16));
 }
 
+// ---- Euclidean batches: per-row (b, b^2 (1 - gamma)) with b = the f32 row norm the mirror used ----
+__global__ void mfma_rownorm_pairs_kernel(const float *__restrict__ row_norms, uint32_t n_rows, uint32_t n_pad,
+                                          float gamma, float2 *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad)
+        return;
+    float b = 0.0f, bsq = 0.0f;
+    if (r < n_rows) {
+        b = row_norms[r];
+        bsq = (b * b) * (1.0f - gamma);
+    }
+    out[r] = make_float2(b, bsq);
+}
+
 // ---- query prep: one wave per query -------------------------------------------------------
 __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
-                                       uint16_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad)
+                                       uint16_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad,
+                                       float *__restrict__ q_norm)
 {
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -108,8 +125,10 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
         s += __shfl_xor(s, o, 64);
     const float n1 = __builtin_sqrtf(s);
     const bool ok = (n1 > 0.0f) && (n1 < __uint_as_float(0x7f800000u));
-    if (lane == 0)
+    if (lane == 0) {
         q_bad[q] = ok ? 0 : 1;
+        q_norm[q] = ok ? n1 : 0.0f; // the scalar the mirror row was divided by (Euclidean epilogue + check)
+    }
     if (!ok)
         return; // mirror stays zero (memset by the host)
     for (uint32_t k = lane; k < dim; k += 64) {
@@ -328,12 +347,20 @@ __global__ __launch_bounds__(128 * WM) void mfma_prefilter_kernel(const uint4 *_
 // KU=4: 2 x 64 KiB), same counted-vmcnt protocol as above.
 // Candidate lists: list = strip * 4 + wave_m * 2 + (lane >> 5); row position in the 10 low
 // mantissa bits = tile-in-strip (4 bits) | mi (2 bits) | accumulator register (4 bits).
-template <int KU, int NSTAGE>
+//
+// MODE 0 (Cosine): the candidate score is s~ itself.  MODE 1 (Euclidean): the same contraction, but
+// the epilogue turns s~ into an UPPER bound of  V = 2 q.x - ||x||^2  (D^2 = ||q||^2 - V, so larger V =
+// closer):  key = 2a * (b * (s~ + eps_e)) - b^2 (1 - gamma), a / b = the norms the two mirrors were
+// divided by, eps_e >= |s~ - q.x / (a b)|, gamma covering the f32 error of b^2 vs ||x||^2 and of the
+// three roundings here.  rn2[row] = (b, b^2 (1 - gamma)).
+template <int KU, int NSTAGE, int MODE>
 __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__restrict__ A,
                                                                 const uint4 *__restrict__ B,
                                                                 float *__restrict__ cand, uint32_t n_rows,
                                                                 uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
-                                                                uint32_t nq, uint32_t n_lists, uint32_t strip_tiles)
+                                                                uint32_t nq, uint32_t n_lists, uint32_t strip_tiles,
+                                                                const float2 *__restrict__ rn2,
+                                                                const float *__restrict__ q_norm, float eps_e)
 {
     constexpr uint32_t TROWS = 256u, TQ = 256u;
     constexpr uint32_t A_UNITS = 8u * KU, UNITS = 16u * KU;
@@ -408,6 +435,14 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                 acc[mi][ni][r] = 0.0f;
     const float ninf = __uint_as_float(0xff800000u);
     float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
+    float cq[2] = {0.0f, 0.0f}; // MODE 1: 2a per query column
+    if (MODE == 1) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
+            cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
+        }
+    }
 
     auto kstep = [&](auto jc, uint32_t it) {
         constexpr int J = decltype(jc)::value;
@@ -462,22 +497,35 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t idx = (ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r;
-                        float sp = __uint_as_float((__float_as_uint(acc[mi][ni][r]) & ~kIdxMask) | idx);
-                        if (ragged) {
-                            const uint32_t row = tile_row0 + wave_m * 128u + (uint32_t)mi * 32u + ((uint32_t)r & 3u) +
-                                                 8u * ((uint32_t)r >> 2) + 4u * (lane >> 5);
-                            if (row >= n_rows)
-                                sp = ninf;
-                        }
-                        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
-                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
-                        m1[ni] = fmaxf(m1[ni], sp);
-                        acc[mi][ni][r] = 0.0f;
+                for (int rq = 0; rq < 4; ++rq) {
+                    // accumulator registers 4 rq .. 4 rq + 3 are 4 consecutive rows
+                    const uint32_t row4 = tile_row0 + wave_m * 128u + (uint32_t)mi * 32u + 8u * (uint32_t)rq +
+                                          4u * (lane >> 5);
+                    float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == 1) { // 32-byte aligned: row4 % 4 == 0, rn2 padded to the tile
+                        const float4 p0 = *(const float4 *)(rn2 + row4);
+                        const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
+                        bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
+                        bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
                     }
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int r = rq * 4 + rl;
+                            const uint32_t idx = (ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r;
+                            float v = acc[mi][ni][r];
+                            if (MODE == 1)
+                                v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
+                            float sp = __uint_as_float((__float_as_uint(v) & ~kIdxMask) | idx);
+                            if (ragged && row4 + (uint32_t)rl >= n_rows)
+                                sp = ninf;
+                            m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+                            m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
+                            m1[ni] = fmaxf(m1[ni], sp);
+                            acc[mi][ni][r] = 0.0f;
+                        }
+                }
         }
     };
 
@@ -578,13 +626,13 @@ __device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32
            4u * half;
 }
 
-template <int DTYPE, typename TopK>
+template <int DTYPE, int METRIC, typename TopK>
 __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms, const float *__restrict__ queries,
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, float eps, uint64_t row_base, uint64_t id_base,
-    uint32_t strip_tiles, uint32_t wm, uint32_t wave_rows)
+    uint32_t strip_tiles, uint32_t wm, uint32_t wave_rows, const float *__restrict__ q_norm, float gamma)
 {
     constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
     extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)]
@@ -625,15 +673,20 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
         for (uint32_t c = 0; c < d_chunks; ++c) {
             const uint4 v = p[(size_t)c * 64u];
             if (DTYPE == VFSX_I8)
-                acc_chunk_i8<VFSX_COSINE, true, 1>(acc, v, qv + c * EPC, 0, lut_lane);
+                acc_chunk_i8<METRIC, true, 1>(acc, v, qv + c * EPC, 0, lut_lane);
             else
-                acc_chunk_f32<VFSX_COSINE, true, 1>(acc, v, qv + c * EPC, 0);
+                acc_chunk_f32<METRIC, true, 1>(acc, v, qv + c * EPC, 0);
         }
         uint64_t comp = kSentinel;
         if (in_range) {
-            const float qn = f_sqrt(acc[0].qq);
-            const float den = f_mul(qn, row_norms[row]);
-            const float dist = f_sub(1.0f, f_div(acc[0].a, den)); // rank.rs:299
+            float dist;
+            if (METRIC == VFSX_EUCLIDEAN) {
+                dist = f_sqrt(acc[0].a); // rank.rs:286
+            } else {
+                const float qn = f_sqrt(acc[0].qq);
+                const float den = f_mul(qn, row_norms[row]);
+                dist = f_sub(1.0f, f_div(acc[0].a, den)); // rank.rs:299
+            }
             comp = ((uint64_t)dist_key(dist) << 32) | row;
         }
         top.offer(comp);
@@ -687,9 +740,21 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     // safety check.  A row r that was not re-scored can only belong to the exact top-k if
     // dist_r <= D_k, i.e. cos_ref(r) >= c_k = 1 - D_k, hence (|s~ - cos_ref| <= eps) s~_r >= c_k - eps.
     const float dk = s_dk;
-    const float thr = (1.0f - dk) - eps;
     bool bad = !(dk == dk) || !(dk < __uint_as_float(0x7f800000u)); // fewer than k exact hits / NaN
-    const bool above = valid && score >= thr;
+    bool above;
+    if (METRIC == VFSX_EUCLIDEAN) {
+        // A row's key' (the prefilter's upper bound of V = 2 q.x - ||x||^2 with its 10 low mantissa bits
+        // replaced) bounds V by key' + 2^-12 |key'|.  It can only enter the exact top-k if
+        // V >= ||q||^2 - D_k^2, where (f32 error of the reference's sum, of a and of D_k, all <= gamma)
+        // ||q||^2 >= a^2 (1 - gamma) and the true D_k^2 <= dk^2 (1 + gamma).  Evaluated in f64.
+        const double a = (double)q_norm[q], g = (double)gamma;
+        const double vk_low = a * a * (1.0 - g) - (double)dk * (double)dk * (1.0 + g);
+        const double sc = (double)score;
+        above = valid && (sc + 0x1p-12 * (sc < 0.0 ? -sc : sc) >= vk_low);
+    } else {
+        const float thr = (1.0f - dk) - eps;
+        above = valid && score >= thr;
+    }
     // (1) rows listed but not selected score <= the worst selected one (sel is sorted, full => index kp-1)
     if (ci == kp - 1u && valid && above)
         bad = true;
@@ -737,30 +802,52 @@ hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_n
 }
 
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                  int *q_bad, hipStream_t s)
+                                  int *q_bad, float *q_norm, hipStream_t s)
 {
     hipLaunchKernelGGL(mfma_query_prep_kernel, dim3(nq), dim3(64), 0, s, d_queries, nq, dim, (uint16_t *)q_mirror, KS,
-                       q_bad);
+                       q_bad, q_norm);
     return hipGetLastError();
 }
 
+hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
+                                     hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_rownorm_pairs_kernel, dim3((n_pad + 255u) / 256u), dim3(256), 0, s, row_norms, n_rows,
+                       n_pad, gamma, (float2 *)out);
+    return hipGetLastError();
+}
+
+// euclid != 0: Euclidean upper-bound epilogue (256 x 256 kernels only); rn2 / q_norm / eps_e as in the kernel
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
-                                 const MfmaGeometry &g, uint32_t nq, hipStream_t s)
+                                 const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
+                                 const float *q_norm, float eps_e, hipStream_t s)
 {
     const uint32_t n_qtiles = (nq + g.tile_queries - 1) / g.tile_queries;
     const dim3 grid(g.n_strips * n_qtiles);
-    if (g.variant == 0)
-        hipLaunchKernelGGL((mfma_prefilter256_kernel<2, 4>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror,
-                           cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
-    else if (g.variant == 1)
-        hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror,
-                           cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
-    else if (g.wm == 4)
-        hipLaunchKernelGGL((mfma_prefilter_kernel<4, 3>), grid, dim3(512), 0, s, mirror, (const uint4 *)q_mirror, cand,
-                           n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+    const uint4 *qm = (const uint4 *)q_mirror;
+    const float2 *rn = (const float2 *)rn2;
+    if (euclid && g.variant > 1u)
+        return hipErrorInvalidValue;
+#define VFSX_PF256(KU, NS, MODE)                                                                                   \
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<KU, NS, MODE>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,   \
+                       g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e)
+    if (g.variant == 0) {
+        if (euclid)
+            VFSX_PF256(2, 4, 1);
+        else
+            VFSX_PF256(2, 4, 0);
+    } else if (g.variant == 1) {
+        if (euclid)
+            VFSX_PF256(4, 2, 1);
+        else
+            VFSX_PF256(4, 2, 0);
+    } else if (g.wm == 4)
+        hipLaunchKernelGGL((mfma_prefilter_kernel<4, 3>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows, g.n_rowtiles,
+                           g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
     else
-        hipLaunchKernelGGL((mfma_prefilter_kernel<2, 2>), grid, dim3(256), 0, s, mirror, (const uint4 *)q_mirror, cand,
-                           n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+        hipLaunchKernelGGL((mfma_prefilter_kernel<2, 2>), grid, dim3(256), 0, s, mirror, qm, cand, n_rows, g.n_rowtiles,
+                           g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+#undef VFSX_PF256
     return hipGetLastError();
 }
 
@@ -783,14 +870,23 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
 {
     const uint32_t list_stride = a.k > 64u ? a.k : 64u;
     const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
-    if (dtype == VFSX_I8)
-        hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_I8, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
-                           a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
-                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows);
-    else
-        hipLaunchKernelGGL((mfma_rescore_kernel<VFSX_F32, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,
-                           a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,
-                           a.d_chunks, a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows);
+#define VFSX_RESCORE(DT, M)                                                                                          \
+    hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,           \
+                       a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks,    \
+                       a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows,         \
+                       a.q_norm, a.gamma)
+    if (dtype == VFSX_I8) {
+        if (a.euclid)
+            VFSX_RESCORE(VFSX_I8, VFSX_EUCLIDEAN);
+        else
+            VFSX_RESCORE(VFSX_I8, VFSX_COSINE);
+    } else {
+        if (a.euclid)
+            VFSX_RESCORE(VFSX_F32, VFSX_EUCLIDEAN);
+        else
+            VFSX_RESCORE(VFSX_F32, VFSX_COSINE);
+    }
+#undef VFSX_RESCORE
     return hipGetLastError();
 }
 
