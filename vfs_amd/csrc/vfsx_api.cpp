@@ -166,7 +166,7 @@ struct vfsx_corpus {
     DeviceBuf<float> q_norm;
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 64;
-    uint32_t mfma_wm = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
+    uint32_t mfma_variant = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
     DeviceBuf<float> cand;
@@ -205,6 +205,23 @@ void reserve_rows(vfsx_corpus *c, uint64_t want_rows)
     uint4 *nc = nullptr;
     float *nn = nullptr;
     uint64_t *ni = nullptr;
+    struct Guard { // a failed allocation / copy below must not leak the new blocks
+        uint4 *&a;
+        float *&b;
+        uint64_t *&c;
+        bool armed = true;
+        ~Guard()
+        {
+            if (!armed)
+                return;
+            if (a)
+                (void)hipFree(a);
+            if (b)
+                (void)hipFree(b);
+            if (c)
+                (void)hipFree(c);
+        }
+    } guard{nc, nn, ni};
     HIP_CHECK(hipMalloc((void **)&nc, c->corpus_bytes(cap)));
     HIP_CHECK(hipMalloc((void **)&nn, cap * sizeof(float)));
     if (c->explicit_ids)
@@ -221,6 +238,7 @@ void reserve_rows(vfsx_corpus *c, uint64_t want_rows)
                                      c->stream));
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    guard.armed = false;
     if (c->d_corpus)
         HIP_CHECK(hipFree(c->d_corpus));
     if (c->d_norms)
@@ -471,7 +489,7 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
 {
     if (c->mirror_rows == c->n_rows && c->d_mirror)
         return;
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_wm);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_variant);
     if (g.mirror_bytes > c->mirror_bytes) {
         free_mirror(c);
         HIP_CHECK(hipMalloc((void **)&c->d_mirror, g.mirror_bytes));
@@ -510,7 +528,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 {
     use_device(c);
     ensure_mirror(c, s);
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_wm);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_variant);
     const uint32_t kp = k <= 8 ? 64u : (k <= 32 ? 128u : 256u);
     const float eps = vfsx::mfma_epsilon(g.k_pad);
     const int euclid = is_cosine(metric) ? 0 : 1;
@@ -610,7 +628,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     if (!d_queries || !d_hits)
         fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
     // Cosine on every prefilter kernel; Euclidean (the reference's metric or its Simd twin) on the 256 x 256 ones
-    const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && c->mfma_wm <= 1u);
+    const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && c->mfma_variant <= 1u);
     const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok) {
@@ -697,7 +715,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
-        c->mfma_wm = (uint32_t)std::min<uint64_t>(3, env_u64("VFSX_MFMA_VARIANT", 1));
+        c->mfma_variant = (uint32_t)std::min<uint64_t>(3, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)
@@ -806,6 +824,8 @@ int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64
 {
     return guarded([&] {
         checked(c);
+        if (n && (!rows || !out))
+            fail(VFSX_ERR_INVALID_VECTOR, "null buffer");
         for (uint64_t i = 0; i < n; ++i) {
             if (rows[i] >= c->n_rows)
                 fail(VFSX_ERR_INVALID_VECTOR, "row index out of range");
