@@ -403,26 +403,49 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     // instead of as a burst behind the barrier.
     const bool a_wave = wave < 4u;
     const uint32_t lane16 = lane * 16u;
-    auto stage_rsrc = [&](uint32_t it) -> __amdgpu_buffer_rsrc_t {
-        const uint32_t tile = tile0 + it / KT;
-        const uint4 *base = a_wave ? A + (size_t)tile * 8u * KS * 64u : B + (size_t)qtile * 8u * KS * 64u;
-        return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00020000);
-    };
-    auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t kt, uint4 *dst, uint32_t u) {
-        const uint32_t unit = (wave & 3u) * G + u; // 0 .. 8 KU - 1, wave-uniform
+    // All bookkeeping below is wave-uniform and incremental (SGPRs, a handful of s_add per K-step):
+    // per-piece constants, the next stage's K offset and tile base, the current K-step's position.
+    uint32_t pc_soff[G], pc_lds[G];
+#pragma unroll
+    for (uint32_t u = 0; u < G; ++u) {
+        const uint32_t unit = (wave & 3u) * G + u; // 0 .. 8 KU - 1
         const uint32_t grp = unit / KU, ks = unit % KU;
-        const uint32_t soff = ((grp * KS) + kt * KU + ks) * 1024u;
+        pc_soff[u] = (grp * KS + ks) * 1024u;
+        pc_lds[u] = ((a_wave ? 0u : A_UNITS) + unit) * 1024u;
+    }
+    const uint32_t tile_bytes = 8u * KS * 1024u; // one 256-row tile of the mirror
+    uintptr_t nx_base = a_wave ? (uintptr_t)A + (uintptr_t)tile0 * tile_bytes : (uintptr_t)B + (uintptr_t)qtile * tile_bytes;
+    uint32_t nx_idx = 0, nx_koff = 0; // next stage to issue: index, byte offset of its K-slice inside a unit row
+    auto next_rsrc = [&]() -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, 0xffffffff, 0x00020000);
+    };
+    auto advance = [&]() { // past the last stage: stay (the redundant re-issue keeps the vmcnt arithmetic constant)
+        if (nx_idx + 1u < n_it) {
+            ++nx_idx;
+            nx_koff += KU * 1024u;
+            if (nx_koff == KS * 1024u) {
+                nx_koff = 0;
+                if (a_wave)
+                    nx_base += tile_bytes;
+            }
+        }
+    };
+    auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t koff, uint32_t slot_base, uint32_t u) {
         // LDS destination laundered: see glds16_untracked
-        uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(dst + ((a_wave ? 0u : A_UNITS) + unit) * 64u);
+        uint32_t a = slot_base + pc_lds[u];
         asm volatile("" : "+s"(a));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
-                                                 (int)lane16, (int)soff, 0, 0);
+                                                 (int)lane16, (int)(pc_soff[u] + koff), 0, 0);
     };
-    auto stage = [&](uint32_t it, uint4 *dst) {
-        const __amdgpu_buffer_rsrc_t rsrc = stage_rsrc(it);
+    auto lds_addr = [&](uint4 *p) -> uint32_t {
+        return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)p;
+    };
+    auto stage = [&](uint4 *dst) {
+        const __amdgpu_buffer_rsrc_t rsrc = next_rsrc();
 #pragma unroll
         for (uint32_t u = 0; u < G; ++u)
-            stage_piece(rsrc, it % KT, dst, u);
+            stage_piece(rsrc, nx_koff, lds_addr(dst), u);
+        advance();
     };
 
     f32x16 acc[4][2];
@@ -435,6 +458,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                 acc[mi][ni][r] = 0.0f;
     const float ninf = __uint_as_float(0xff800000u);
     float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
+    uint32_t keep_mask = ~kIdxMask;
+    asm volatile("" : "+v"(keep_mask)); // keep it in a VGPR (see the epilogue)
+    uint32_t cur_kt = 0, cur_ts = 0;    // position of the running K-step inside the strip
     float cq[2] = {0.0f, 0.0f}; // MODE 1: 2a per query column
     if (MODE == 1) {
 #pragma unroll
@@ -443,6 +469,47 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
         }
     }
+
+    auto fold_tile = [&](auto ragged_c, uint32_t ts, uint32_t tile_row0) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                // accumulator registers 4 rq .. 4 rq + 3 are 4 consecutive rows
+                const uint32_t row4 = tile_row0 + wave_m * 128u + (uint32_t)mi * 32u + 8u * (uint32_t)rq + 4u * (lane >> 5);
+                float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == 1) { // 32-byte aligned: row4 % 4 == 0, rn2 padded to the tile
+                    const float4 p0 = *(const float4 *)(rn2 + row4);
+                    const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
+                    bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
+                    bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
+                }
+#pragma unroll
+                for (int rl = 0; rl < 4; ++rl) {
+                    const int r = rq * 4 + rl;
+                    // the index is wave-uniform: keep it in an SGPR so that mask (VGPR) + index is ONE
+                    // v_and_or_b32 per element
+                    const uint32_t idx =
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r));
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float v = acc[mi][ni][r];
+                        if (MODE == 1)
+                            v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
+                        float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
+                        if (RAGGED && row4 + (uint32_t)rl >= n_rows)
+                            sp = ninf;
+                        // sorted-triple insertion (m1 >= m2 >= m3): two v_med3_f32 and one v_max_f32; the
+                        // max as asm because fmaxf on bit-assembled floats costs two canonicalising v_max more
+                        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
+                        asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
+                        acc[mi][ni][r] = 0.0f;
+                    }
+                }
+            }
+    };
 
     auto kstep = [&](auto jc, uint32_t it) {
         constexpr int J = decltype(jc)::value;
@@ -461,10 +528,10 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory"); // no fragment read may be hoisted above the barrier
-        const uint32_t it_n = min(it + (uint32_t)(NSTAGE - 1), n_it - 1u);
-        const __amdgpu_buffer_rsrc_t rsrc_n = stage_rsrc(it_n);
-        const uint32_t kt_n = it_n % KT;
-        uint4 *wr = slot(JW);
+        const __amdgpu_buffer_rsrc_t rsrc_n = next_rsrc();
+        const uint32_t koff_n = nx_koff;
+        const uint32_t wr = lds_addr(slot(JW));
+        advance();
 #pragma unroll
         for (uint32_t ks = 0; ks < (uint32_t)KU; ++ks) {
             bf16x8 a[4], b[2];
@@ -480,7 +547,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             if (ks * PPK < G) {
 #pragma unroll
                 for (uint32_t u = 0; u < PPK; ++u)
-                    stage_piece(rsrc_n, kt_n, wr, ks * PPK + u);
+                    stage_piece(rsrc_n, koff_n, wr, ks * PPK + u);
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -488,52 +555,25 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (it % KT == KT - 1u) {
+        if (++cur_kt == KT) {
             // tile finished: fold its 128 scores per lane into the running top-3 of each query column.
             // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-            const uint32_t ts = it / KT;
+            const uint32_t ts = cur_ts;
+            cur_kt = 0;
+            ++cur_ts;
             const uint32_t tile_row0 = (tile0 + ts) * TROWS;
-            const bool ragged = tile_row0 + TROWS > n_rows;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    // accumulator registers 4 rq .. 4 rq + 3 are 4 consecutive rows
-                    const uint32_t row4 = tile_row0 + wave_m * 128u + (uint32_t)mi * 32u + 8u * (uint32_t)rq +
-                                          4u * (lane >> 5);
-                    float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == 1) { // 32-byte aligned: row4 % 4 == 0, rn2 padded to the tile
-                        const float4 p0 = *(const float4 *)(rn2 + row4);
-                        const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
-                        bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
-                        bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
-                    }
-#pragma unroll
-                    for (int rl = 0; rl < 4; ++rl)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int r = rq * 4 + rl;
-                            const uint32_t idx = (ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r;
-                            float v = acc[mi][ni][r];
-                            if (MODE == 1)
-                                v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
-                            float sp = __uint_as_float((__float_as_uint(v) & ~kIdxMask) | idx);
-                            if (ragged && row4 + (uint32_t)rl >= n_rows)
-                                sp = ninf;
-                            m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
-                            m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
-                            m1[ni] = fmaxf(m1[ni], sp);
-                            acc[mi][ni][r] = 0.0f;
-                        }
-                }
+            if (tile_row0 + TROWS > n_rows)
+                fold_tile(std::true_type{}, ts, tile_row0); // last, ragged tile: rows >= n_rows masked
+            else
+                fold_tile(std::false_type{}, ts, tile_row0);
         }
     };
 
-    stage(0, lds_s0); // n_it >= 2 (KS >= 4, KU <= 4 ... KT >= 1; ntiles >= 1): clamp below keeps it general
+    stage(lds_s0); // stages 0 .. NSTAGE-2 (advance() clamps at the last one)
     if (NSTAGE > 2)
-        stage(min(1u, n_it - 1u), lds_s1);
+        stage(lds_s1);
     if (NSTAGE > 3)
-        stage(min(2u, n_it - 1u), lds_s2);
+        stage(lds_s2);
     // n_it % NSTAGE == 0 (the host pads K so that KT is a multiple of NSTAGE): a straight-line round
     for (uint32_t it = 0; it < n_it; it += NSTAGE) {
         kstep(std::integral_constant<int, 0>{}, it);
