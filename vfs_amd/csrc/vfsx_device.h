@@ -114,6 +114,69 @@ struct WaveTopKReg {
         if (lane_id() < k)
             dst[lane_id() * stride] = e;
     }
+    // publish the list (kSentinel padded to 64 entries) into this wave's LDS row
+    __device__ __forceinline__ void spill(uint64_t *mine) const
+    {
+        mine[lane_id()] = kSentinel;
+        store(mine);
+    }
+};
+
+// 64 < k <= 128: two registers per lane (e0 = ranks 0..63, e1 = ranks 64..127); an insert is two
+// ballots, two DPP shifts and the carry of rank 63 into rank 64 -- about twice the k <= 64 cost and
+// still several times cheaper than the LDS list below.
+struct WaveTopKReg2 {
+    static constexpr bool kInRegisters = true;
+    uint64_t e0, e1;
+    uint64_t tau;
+    uint32_t k;
+    __device__ __forceinline__ void init(uint32_t k_, uint64_t *)
+    {
+        k = k_;
+        e0 = e1 = kSentinel;
+        tau = kSentinel;
+    }
+    __device__ __forceinline__ void insert(uint64_t c)
+    {
+        const uint32_t lane = lane_id();
+        const uint32_t p = (uint32_t)__popcll(__ballot(e0 < c)) + (uint32_t)__popcll(__ballot(e1 < c));
+        if (p < 64u) { // wave-uniform
+            const uint64_t carry = readlane64(e0, 63);
+            const uint64_t up0 = shfl_up1_u64(e0), up1 = shfl_up1_u64(e1);
+            e0 = lane < p ? e0 : (lane == p ? c : up0);
+            e1 = lane == 0u ? carry : up1;
+        } else {
+            const uint32_t q = p - 64u;
+            const uint64_t up1 = shfl_up1_u64(e1);
+            e1 = lane < q ? e1 : (lane == q ? c : up1);
+        }
+        tau = k <= 64u ? readlane64(e0, k - 1u) : readlane64(e1, k - 65u);
+    }
+    __device__ __forceinline__ void offer(uint64_t comp)
+    {
+        uint64_t m = __ballot(comp < tau);
+        while (m) {
+            uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            uint64_t c = readlane64(comp, l);
+            if (c < tau)
+                insert(c);
+        }
+    }
+    __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
+    {
+        if (lane_id() < k)
+            dst[lane_id() * stride] = e0;
+        if (lane_id() + 64u < k)
+            dst[(lane_id() + 64u) * stride] = e1;
+    }
+    // publish the list (kSentinel padded to 128 entries) into this wave's LDS row
+    __device__ __forceinline__ void spill(uint64_t *mine) const
+    {
+        mine[lane_id()] = kSentinel;
+        mine[lane_id() + 64u] = kSentinel;
+        store(mine);
+    }
 };
 
 // any k: the list lives in LDS (one per wave), ascending, kSentinel padded.
@@ -177,6 +240,7 @@ struct WaveTopKLds {
         for (uint32_t i = lane_id(); i < k; i += 64)
             dst[i * stride] = L[i];
     }
+    __device__ __forceinline__ void spill(uint64_t *) const {} // the list already lives in the wave's LDS row
 };
 
 // ---- distance accumulation -----------------------------------------------------

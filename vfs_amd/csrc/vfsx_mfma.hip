@@ -630,10 +630,7 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
     }
     uint64_t *mine = dyn_lds + wave * list_stride;
     __syncthreads();
-    if (TopK::kInRegisters) {
-        mine[lane] = kSentinel;
-        top.store(mine);
-    }
+    top.spill(mine);
     __syncthreads();
     if (wave == 0) {
         bool alive = lane >= 1 && lane < (uint32_t)WAVES;
@@ -710,7 +707,22 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
         const uint32_t r = in_range ? row : 0u;
         const uint4 *__restrict__ p = corpus + (size_t)(r >> 6) * d_chunks * 64u + (r & 63u);
         Acc acc[1] = {Acc{0.0f, 0.0f}};
-        for (uint32_t c = 0; c < d_chunks; ++c) {
+        // a gather: 16 B per 1 KiB of the row's block, latency-bound -> keep 8 loads in flight
+        uint32_t c = 0;
+        for (; c + 8u <= d_chunks; c += 8u) {
+            uint4 v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u)
+                v[u] = p[(size_t)(c + u) * 64u];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                if (DTYPE == VFSX_I8)
+                    acc_chunk_i8<METRIC, true, 1>(acc, v[u], qv + (c + u) * EPC, 0, lut_lane);
+                else
+                    acc_chunk_f32<METRIC, true, 1>(acc, v[u], qv + (c + u) * EPC, 0);
+            }
+        }
+        for (; c < d_chunks; ++c) {
             const uint4 v = p[(size_t)c * 64u];
             if (DTYPE == VFSX_I8)
                 acc_chunk_i8<METRIC, true, 1>(acc, v, qv + c * EPC, 0, lut_lane);
@@ -899,6 +911,9 @@ hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uin
     const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
     if (kp <= kMaxRegisterK)
         hipLaunchKernelGGL((mfma_select_kernel<WaveTopKReg, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
+                           kp);
+    else if (kp <= 128u)
+        hipLaunchKernelGGL((mfma_select_kernel<WaveTopKReg2, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
                            kp);
     else
         hipLaunchKernelGGL((mfma_select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
