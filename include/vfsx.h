@@ -93,6 +93,11 @@ typedef struct vfsx_corpus vfsx_corpus;
 /* Number of usable HIP devices (0 when there is none; never fails). */
 int vfsx_device_count(void);
 
+/* Start-up check for a host that wants `n_devices` GPUs (one process per GPU passes 1): VFSX_OK when at
+ * least that many gfx950 devices are visible, VFSX_ERR_NO_DEVICE otherwise -- the place to fail
+ * loudly at boot (main.rs:47-62 has no counterpart: the reference needs no device).  Allocates nothing. */
+int vfsx_init(int n_devices);
+
 /* Message of the last failure on this thread ("" if none). */
 const char *vfsx_last_error(void);
 

@@ -25,6 +25,7 @@ pub const VFSX_I8: c_int = 1;
 
 extern "C" {
     pub fn vfsx_device_count() -> c_int;
+    pub fn vfsx_init(n_devices: c_int) -> c_int;
     pub fn vfsx_last_error() -> *const c_char;
     pub fn vfsx_corpus_create(dim: u32, dtype: c_int, scale: f32, capacity_rows: u64, device: c_int) -> *mut VfsxCorpus;
     pub fn vfsx_corpus_destroy(c: *mut VfsxCorpus);

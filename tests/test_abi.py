@@ -41,6 +41,8 @@ def test_no_gpu_fails_loudly():
         vfs_amd.Corpus(16)
     assert e.value.code == _lib.ERR_NO_DEVICE
     assert "no CPU fallback" in str(e.value)
+    assert lib.vfsx_init(1) == _lib.ERR_NO_DEVICE            # the boot-time check says the same
+    assert b"no CPU fallback" in lib.vfsx_last_error()
 
 
 def test_product_never_imports_oracle():

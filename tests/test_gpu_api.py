@@ -187,3 +187,12 @@ def test_large_k_batch_splits_into_several_launches(oracle):
             assert (ids[qi] == oi).all()
             assert (dist[qi].view(np.uint32) == od.view(np.uint32)).all()
     c.close()
+
+
+def test_vfsx_init_counts_devices():
+    import vfs_amd
+    from vfs_amd import _lib
+    lib = vfs_amd.load()
+    n = lib.vfsx_device_count()
+    assert n >= 1 and lib.vfsx_init(1) == _lib.OK and lib.vfsx_init(n) == _lib.OK
+    assert lib.vfsx_init(n + 1) == _lib.ERR_NO_DEVICE

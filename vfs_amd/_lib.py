@@ -23,7 +23,7 @@ MAX_K = 1024
 
 # every symbol include/vfsx.h declares
 SYMBOLS = (
-    "vfsx_device_count", "vfsx_last_error", "vfsx_version", "vfsx_corpus_create",
+    "vfsx_device_count", "vfsx_init", "vfsx_last_error", "vfsx_version", "vfsx_corpus_create",
     "vfsx_corpus_destroy", "vfsx_corpus_append", "vfsx_corpus_append_quantize",
     "vfsx_corpus_rows", "vfsx_corpus_dim", "vfsx_corpus_dtype", "vfsx_corpus_set_row_base",
     "vfsx_corpus_get_rows_f32", "vfsx_corpus_get_rows_raw", "vfsx_corpus_get_ids",
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     vp, u64p, f32p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     hitp = C.POINTER(Hit)
     lib.vfsx_device_count.restype = C.c_int
+    lib.vfsx_init.restype = C.c_int
+    lib.vfsx_init.argtypes = [C.c_int]
     lib.vfsx_last_error.restype = C.c_char_p
     lib.vfsx_version.restype = C.c_char_p
     lib.vfsx_corpus_create.restype = vp

@@ -699,6 +699,25 @@ extern "C" {
 
 int vfsx_device_count(void) { return device_count_quiet(); }
 
+int vfsx_init(int n_devices)
+{
+    return guarded([&] {
+        if (n_devices < 0)
+            fail(VFSX_ERR_INVALID_VECTOR, "negative device count");
+        const int have = device_count_quiet();
+        if (have < std::max(n_devices, 1))
+            fail(VFSX_ERR_NO_DEVICE, "vfsx_init: " + std::to_string(n_devices) + " HIP device(s) wanted, " +
+                                         std::to_string(have) + " visible (vfsx has no CPU fallback)");
+        for (int d = 0; d < std::max(n_devices, 1); ++d) {
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, d));
+            if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("VFSX_ALLOW_ANY_ARCH"))
+                fail(VFSX_ERR_NO_DEVICE, std::string("vfsx is built for gfx950 only, device ") + std::to_string(d) +
+                                             " is " + prop.gcnArchName);
+        }
+    });
+}
+
 const char *vfsx_last_error(void) { return g_last_error.c_str(); }
 
 const char *vfsx_version(void) { return "vfsx 0.1 gfx950 rb64"; }
