@@ -1,4 +1,4 @@
-"""GPU: parity at BASELINE.json's full single-GPU sizes (C1, C2, C3), against the
+"""GPU: parity at BASELINE.json's full single-GPU sizes (C1-C4, one C5 shard), against the
 oracle on the same synthetic corpus, plus size-independent properties (shard-merge
 equals whole-corpus search; Simd* == scalar; k-prefix property)."""
 import ctypes as C
@@ -118,4 +118,36 @@ def test_c4_10m_x1024_mfma_batch_equals_exact_scan(oracle):
         row = int(ids_m[0, 0]) - 1
         x = oracle.synth_f32(SEED_C, row, 1, d)
         assert bits(oracle.all_distances(x, queries[0], metric))[0] == bits(dist_m[0, :1])[0]
+    c.close()
+
+
+def test_c5_shard_12m5_x768_euclidean_properties(oracle):
+    """BASELINE config 5, one GPU's share (shard 3 of 8 of the 100M x 768 corpus = 38.4 GB).  The
+    oracle cannot scan 9.6e9 elements in seconds, so the full-size check uses size-independent
+    properties: the reported distances are the oracle's for the regenerated winner rows, the list is
+    sorted by (distance, row), rows/ids carry the shard's base, no row of a 400k-row random sample
+    of the shard beats the k-th hit, and k = 100 extends k = 10."""
+    import vfs_amd
+    n, d, shard = 12_500_000, 768, 3
+    lo = shard * n
+    c = vfs_amd.Corpus(d, capacity_rows=n)
+    c.fill_synthetic(SEED_C, n, row0=lo, id0=lo + 1)
+    c.set_row_base(lo)
+    q = oracle.synth_f32(SEED_Q, 11, 1, d)[0]
+    ids, dist, cnt = c.search_batch(q, 10, 0)
+    assert cnt[0] == 10 and (ids[0] > lo).all() and (ids[0] <= lo + n).all()
+    for j in range(10):  # regenerate each winner on the host: the oracle's distance, bit for bit
+        x = oracle.synth_f32(SEED_C, int(ids[0, j]) - 1, 1, d)
+        assert bits(oracle.all_distances(x, q, 0))[0] == bits(dist[0, j:j + 1])[0]
+    assert all((dist[0, j], ids[0, j]) < (dist[0, j + 1], ids[0, j + 1]) for j in range(9))
+    rng = np.random.default_rng(5)
+    for r0 in rng.integers(0, n - 100_000, 4):  # four random 100k-row windows of the shard
+        rows = oracle.synth_f32(SEED_C, lo + int(r0), 100_000, d)
+        oi, od, op = oracle.topk_scan(rows, q, 0, 10)
+        for dd, pp in zip(od, op):  # a sampled row that beats the k-th hit must itself be a hit
+            gid = lo + int(r0) + int(pp) + 1
+            if (dd, gid) < (dist[0, 9], ids[0, 9]):
+                assert gid in ids[0].tolist()
+    ids100, dist100, _ = c.search_batch(q, 100, 2)
+    assert (ids100[0, :10] == ids[0]).all() and (bits(dist100[0, :10]) == bits(dist[0])).all()
     c.close()
