@@ -14,3 +14,13 @@ def test_cxx_ranker_selftest():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert r.stdout.startswith("ok id=1 dist=3.74165")
+
+
+def test_cxx_ranker_parity_against_oracle():
+    """tests/cxx/ranker_parity.cpp: the C++ Ranker mirror vs the linked C oracle -- every method, dense
+    and quantized stores, limits 1..100, ties, the integer-domain extension, the literal batch loop."""
+    exe = os.path.join(ROOT, "tests", "cxx", "ranker_parity")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.strip().splitlines()[-1].startswith("ok ")

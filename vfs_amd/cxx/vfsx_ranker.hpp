@@ -65,6 +65,33 @@ public:
         check(vfsx_corpus_append(h_, rows, ids, n));
     }
 
+    // serializer.rs:77-153 / storage_manager.rs:166-217: stream an existing data/vectors.dat into HBM
+    // (ids and metadata as recorded); returns the records loaded
+    uint64_t load_log(const std::string &path)
+    {
+        uint64_t n = 0;
+        check(vfsx_corpus_load_log(h_, path.c_str(), &n));
+        return n;
+    }
+    // many-query batches on the matrix cores (no reference counterpart; results unchanged)
+    void enable_mfma(bool on = true) { check(vfsx_corpus_enable_mfma(h_, on ? 1 : 0)); }
+
+    // nq queries at once ("A2/A3 + A4 per query", SURVEY.md 8a batch note): flat [nq][k] outputs
+    struct Batch {
+        std::vector<uint64_t> ids;
+        std::vector<float> dist;
+        std::vector<uint32_t> count;
+    };
+    Batch search_batch(const float *queries, uint32_t nq, uint32_t k, int metric)
+    {
+        Batch b;
+        b.ids.resize((size_t)nq * k);
+        b.dist.resize((size_t)nq * k);
+        b.count.resize(nq);
+        check(vfsx_search(h_, queries, nq, k, metric, b.ids.data(), b.dist.data(), b.count.data()));
+        return b;
+    }
+
 private:
     vfsx_corpus *h_ = nullptr;
     uint32_t dim_;
