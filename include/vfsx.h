@@ -205,6 +205,13 @@ int vfsx_log_inspect(const char *path, vfsx_log_info *info);
  */
 int vfsx_corpus_load_log(vfsx_corpus *c, const char *path, uint64_t *n_loaded);
 
+/* The same for records [first_record, first_record + max_records) of the file, in file order: what
+ * one rank of a row-sharded deployment loads (contiguous row ranges, so that
+ * (shard, local row) order equals the reference's scan order).  Earlier records are stepped over by
+ * their length field only. */
+int vfsx_corpus_load_log_range(vfsx_corpus *c, const char *path, uint64_t first_record, uint64_t max_records,
+                               uint64_t *n_loaded);
+
 /*
  * VectorMetadata of a LOCAL row as JSON: {"name":"..","tags":[..],"created_at":".."}
  * (empty strings for rows appended without metadata).  Writes at most cap-1 bytes + NUL;

@@ -26,6 +26,7 @@ pub const VFSX_I8: c_int = 1;
 extern "C" {
     pub fn vfsx_device_count() -> c_int;
     pub fn vfsx_init(n_devices: c_int) -> c_int;
+    pub fn vfsx_corpus_load_log_range(c: *mut VfsxCorpus, path: *const c_char, first_record: u64, max_records: u64, n_loaded: *mut u64) -> c_int;
     pub fn vfsx_last_error() -> *const c_char;
     pub fn vfsx_corpus_create(dim: u32, dtype: c_int, scale: f32, capacity_rows: u64, device: c_int) -> *mut VfsxCorpus;
     pub fn vfsx_corpus_destroy(c: *mut VfsxCorpus);

@@ -219,3 +219,47 @@ def test_restore_without_snapshot_is_500(srv):
     _req(port, "POST", "/init", {"vector_dimension": 4, "truncate_data": True, "quantize": False})
     st, body = _req(port, "POST", "/restore")
     assert st == 500 and body.startswith('{"error":"Failed to load state: I/O error:')
+
+
+def test_log_ranges_as_shards_equal_the_whole_file(tmp_path, oracle):
+    """F1 x 8e: three corpora each load their contiguous record range of one reference-format log
+    (what the ranks of a row-sharded deployment do, vfs_amd.sharded.ShardedCorpus.load_log), search
+    locally and merge by (distance, global row): identical to one corpus holding the whole file."""
+    import torch
+    import vfs_amd
+    from vfs_amd import sharded, vfslog
+    rng = np.random.default_rng(31)
+    n, d = 1000, 24
+    base = rng.uniform(-1, 1, (50, d)).astype(np.float32)
+    rows = base[rng.integers(0, 50, n)]                      # many exact duplicates: ties across shards
+    p = str(tmp_path / "vectors.dat")
+    vfslog.append_records(p, [vfslog.encode_record(5000 + i, r, f"v{i}", ["t"], "2025-04-17T14:11:10Z")
+                              for i, r in enumerate(rows)])
+    whole = vfslog.open_corpus(p)
+    assert len(whole) == n
+    q = rng.uniform(-1, 1, (4, d)).astype(np.float32)
+    k = 20
+    shards = []
+    for lo, hi in sharded.split_rows(n, 3):
+        c = vfs_amd.Corpus(d)
+        assert c.load_log(p, first=lo, count=hi - lo) == hi - lo
+        c.set_row_base(lo)
+        assert c.get_ids([0])[0] == 5000 + lo and c.get_metadata(0)["name"] == f"v{lo}"
+        shards.append(c)
+    dq = torch.from_numpy(q).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for metric in (0, 1):
+        lists = torch.zeros((3, 4, k, 6), dtype=torch.int32, device="cuda")
+        for g, c in enumerate(shards):
+            c.search_device(dq.data_ptr(), 4, k, metric, lists[g].data_ptr(), st)
+        torch.cuda.synchronize()
+        g = lists.cpu().numpy().view(np.uint8).reshape(3, 4, k, 24).view(sharded.HIT_DTYPE).reshape(3, 4, k)
+        merged = sharded.merge_hits_host(g, k)
+        ids, dist, cnt = whole.search_batch(q, k, metric)
+        assert (merged["id"] == ids).all()
+        assert (merged["dist"].view(np.uint32) == dist.view(np.uint32)).all()
+        oi, od, _ = oracle.topk_scan(rows, q[0], metric, k, ids=np.arange(5000, 5000 + n, dtype=np.uint64))
+        assert (ids[0] == oi).all()
+    assert shards[2].load_log(p, first=n + 5, count=10) == 0  # a range past the end loads nothing
+    for c in shards + [whole]:
+        c.close()

@@ -30,7 +30,7 @@ SYMBOLS = (
     "vfsx_corpus_fill_synthetic", "vfsx_search", "vfsx_search_device",
     "vfsx_merge_hits_device", "vfsx_merge_hits_host", "vfsx_corpus_set_profiling",
     "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats",
-    "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_get_metadata_json",
+    "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_load_log_range", "vfsx_corpus_get_metadata_json",
 )
 
 
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
     lib.vfsx_corpus_set_profiling.argtypes = [vp, C.c_int]
     lib.vfsx_log_inspect.argtypes = [C.c_char_p, C.POINTER(LogInfo)]
     lib.vfsx_corpus_load_log.argtypes = [vp, C.c_char_p, u64p]
+    lib.vfsx_corpus_load_log_range.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_uint64, u64p]
     lib.vfsx_corpus_get_metadata_json.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, u64p]
     lib.vfsx_corpus_enable_mfma.argtypes = [vp, C.c_int]
     lib.vfsx_corpus_mfma_stats.argtypes = [vp, u64p, u64p, C.c_int]

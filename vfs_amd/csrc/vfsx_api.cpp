@@ -1135,14 +1135,16 @@ void decode_record(const uint8_t *payload, size_t len, LogRecord &r)
 
 // Walks the file the way load_vectors does (serializer.rs:101-150), minus its 1 KiB window:
 // a marker starts a record, any other byte is skipped, an incomplete trailing record ends the scan.
+// Records with index < first are stepped over by their length only (not decoded); at most max_count
+// records are delivered.  Returns the number of records delivered.
 template <typename F>
-uint64_t walk_log(const MappedFile &f, F &&on_record)
+uint64_t walk_log(const MappedFile &f, F &&on_record, uint64_t first = 0, uint64_t max_count = ~0ull)
 {
     static const uint8_t marker[4] = {0xDE, 0xAD, 0xBE, 0xEF}; // serializer.rs:13
     size_t cur = 0;
-    uint64_t count = 0;
+    uint64_t index = 0, count = 0;
     LogRecord r;
-    while (cur + 4 <= f.n) {
+    while (cur + 4 <= f.n && count < max_count) {
         if (std::memcmp(f.p + cur, marker, 4) != 0) {
             ++cur; // serializer.rs:148
             continue;
@@ -1153,10 +1155,13 @@ uint64_t walk_log(const MappedFile &f, F &&on_record)
         std::memcpy(&len, f.p + cur + 4, 8);
         if (len > f.n - (cur + 12))
             break; // serializer.rs:137-141
-        decode_record(f.p + cur + 12, (size_t)len, r);
-        on_record(r);
+        if (index >= first) {
+            decode_record(f.p + cur + 12, (size_t)len, r);
+            on_record(r);
+            ++count;
+        }
+        ++index;
         cur += 12 + (size_t)len;
-        ++count;
     }
     return count;
 }
@@ -1213,6 +1218,12 @@ int vfsx_log_inspect(const char *path, vfsx_log_info *info)
 
 int vfsx_corpus_load_log(vfsx_corpus *c, const char *path, uint64_t *n_loaded)
 {
+    return vfsx_corpus_load_log_range(c, path, 0, ~0ull, n_loaded);
+}
+
+int vfsx_corpus_load_log_range(vfsx_corpus *c, const char *path, uint64_t first_record, uint64_t max_records,
+                               uint64_t *n_loaded)
+{
     return guarded([&] {
         checked(c);
         if (!path)
@@ -1261,7 +1272,7 @@ int vfsx_corpus_load_log(vfsx_corpus *c, const char *path, uint64_t *n_loaded)
             metas.push_back(r.meta);
             if (ids.size() >= batch_rows)
                 flush();
-        });
+        }, first_record, max_records);
         flush();
         if (n_loaded)
             *n_loaded = total;

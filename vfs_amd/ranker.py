@@ -120,11 +120,13 @@ class Corpus:
         else:
             _lib.check(self._lib.vfsx_corpus_append(self._h, rows.ctypes.data_as(C.c_void_p), idp, rows.shape[0]))
 
-    def load_log(self, path: str) -> int:
-        """Append every record of a VFS `data/vectors.dat` log (serializer.rs:25-153), keeping ids
-        and metadata.  Returns the number of records loaded."""
+    def load_log(self, path: str, first: int = 0, count: Optional[int] = None) -> int:
+        """Append the records of a reference data file (serializer.rs:25-153) -- all of them, or the
+        `count` records starting at record `first` (one shard's contiguous range).  Returns the
+        number of records loaded."""
         n = C.c_uint64(0)
-        _lib.check(self._lib.vfsx_corpus_load_log(self._h, str(path).encode(), C.byref(n)))
+        _lib.check(self._lib.vfsx_corpus_load_log_range(self._h, str(path).encode(), int(first),
+                                                        (1 << 64) - 1 if count is None else int(count), C.byref(n)))
         return int(n.value)
 
     def get_metadata(self, row: int) -> dict:

@@ -96,6 +96,19 @@ class ShardedCorpus:
     def set_row_base(self, row_base: int) -> None:
         self.local.set_row_base(row_base)
 
+    def load_log(self, path: str) -> int:
+        """Every rank loads its contiguous range of the records of one reference data file
+        (split_rows over the record count) and takes that range's start as its row base, so the
+        merged ranking equals a single scan of the whole file.  Returns this rank's record count."""
+        import torch.distributed as dist
+        from . import vfslog
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        lo, hi = split_rows(vfslog.inspect(path)["records"], world)[rank]
+        n = self.local.load_log(path, first=lo, count=hi - lo)
+        self.local.set_row_base(lo)
+        return n
+
     def search(self, d_queries, k: int, metric: int):
         """d_queries: torch float32 cuda tensor [nq, dim]. Returns merged hits tensor [nq,k,6]."""
         import torch
