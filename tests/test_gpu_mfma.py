@@ -196,3 +196,29 @@ def test_mfma_euclidean_needs_the_256_kernels(monkeypatch, oracle):
     oi, od, _ = oracle.topk_scan(rows, queries[5], 0, 10)
     assert (ids[5] == oi).all() and (bits(dist[5]) == bits(od)).all()
     c.close()
+
+
+def test_mfma_backs_off_when_the_check_keeps_failing(oracle):
+    """Every row a near-duplicate of its neighbours: (almost) every query fails the bound check, so the
+    prefilter is wasted work.  The next batches skip it (1, then 3, ... batches) and stay exact."""
+    import vfs_amd
+    rng = np.random.default_rng(9)
+    n, d = 20000, 64
+    center = rng.uniform(-1, 1, d).astype(np.float32)
+    rows = (center + rng.normal(0, 1e-4, (n, d))).astype(np.float32)
+    queries = (center + rng.normal(0, 1e-4, (128, d))).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    c.enable_mfma(True)
+    c.mfma_stats(reset=True)
+    ids1, dist1, _ = c.search_batch(queries, 10, 1)
+    mq, fb = c.mfma_stats()
+    assert mq == 128 and fb > 64
+    ids2, dist2, _ = c.search_batch(queries, 10, 1)          # backed off: the exact scan, no prefilter
+    assert c.mfma_stats()[0] == 128
+    ids3, dist3, _ = c.search_batch(queries, 10, 1)          # probes again
+    assert c.mfma_stats()[0] == 256
+    for ids, dist in ((ids1, dist1), (ids2, dist2), (ids3, dist3)):
+        oi, od, _ = oracle.topk_scan(rows, queries[3], 1, 10)
+        assert (ids[3] == oi).all() and (bits(dist[3]) == bits(od)).all()
+    c.close()

@@ -174,6 +174,10 @@ struct vfsx_corpus {
     DeviceBuf<uint64_t> sel;
     std::vector<int> h_flags;
     uint64_t mfma_queries = 0, mfma_fallbacks = 0;
+    // back-off: when most of a batch failed the bound check (near-duplicate-heavy data), the prefilter
+    // was wasted work; skip it for the next `mfma_backoff` batches, doubling the pause while it keeps
+    // happening (1, 3, 7, ... 63 batches), and probe again afterwards
+    uint32_t mfma_backoff = 0, mfma_backoff_next = 0;
 
     // profiling
     bool profiling = false;
@@ -621,6 +625,17 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     c->mfma_queries += nq;
+    {
+        uint32_t flagged = 0;
+        for (uint32_t q = 0; q < nq; ++q)
+            flagged += c->h_flags[q] ? 1u : 0u;
+        if (flagged * 2u > nq) {
+            c->mfma_backoff_next = std::min<uint32_t>(c->mfma_backoff_next * 2u + 1u, 63u);
+            c->mfma_backoff = c->mfma_backoff_next;
+        } else {
+            c->mfma_backoff_next = 0;
+        }
+    }
     // exact scan for the queries the check flagged, in contiguous runs (not part of the
     // profiled kernel: the event brackets on this path time the prefilter GEMM only)
     const bool prof_saved = c->profiling;
@@ -655,6 +670,11 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && c->mfma_variant <= 1u);
     const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
+    if (mfma_ok && c->mfma_backoff > 0) {
+        --c->mfma_backoff; // see vfsx_corpus::mfma_backoff
+        exact_search_device(c, d_queries, nq, k, metric, d_hits, s);
+        return;
+    }
     if (mfma_ok) {
         use_device(c);
         ensure_mirror(c, s);
@@ -986,6 +1006,7 @@ int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
         checked(c);
         use_device(c);
         c->mfma_enabled = enable != 0;
+        c->mfma_backoff = c->mfma_backoff_next = 0;
         if (!enable)
             free_mirror(c);
         else if (c->n_rows)
