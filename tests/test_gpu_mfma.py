@@ -111,9 +111,9 @@ def test_mfma_bad_queries_and_append_after_enable(oracle):
     c.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_mfma_every_prefilter_kernel(oracle, monkeypatch, variant):
-    """The four prefilter kernels (256x256 tile with a 4-slot / 2-slot ring, 256x128, 128x128;
+    """The five prefilter kernels (256x256 tile with a 4-slot / 2-slot ring, 256x128, 128x128, 256x256 on 16x16x32 MFMA;
     VFSX_MFMA_VARIANT, read when the corpus is created) all feed the same exact re-score."""
     import vfs_amd
     monkeypatch.setenv("VFSX_MFMA_VARIANT", str(variant))

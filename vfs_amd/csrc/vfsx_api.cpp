@@ -527,9 +527,10 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
         HIP_CHECK(hipMalloc((void **)&c->d_mirror_bad, sizeof(int)));
     HIP_CHECK(hipMemsetAsync(c->d_mirror_bad, 0, sizeof(int), s));
     HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror, (uint32_t)c->n_rows,
-                                       c->dim, c->d_chunks, g.KS, (uint32_t)(g.mirror_bytes / ((size_t)g.k_pad * 2u * 32u)),
+                                       c->dim, c->d_chunks, g.KS,
+                                       (uint32_t)(g.mirror_bytes / ((size_t)g.k_pad * 2u * g.unit_rows)), g.unit_rows,
                                        c->d_mirror_bad, s));
-    if (g.variant <= 1u) { // Euclidean batches (256 x 256 kernels only)
+    if (g.tile_queries == 256u) { // Euclidean batches (256 x 256 kernels only)
         const size_t n_pad = (size_t)g.n_rowtiles * g.wave_rows * g.wm;
         if (n_pad > c->rn2_rows) {
             if (c->d_rn2)
@@ -589,7 +590,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         const uint32_t qn_pad = (qn + 255u) / 256u * 256u;
         HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * 2u, s));
         HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
-                                               c->q_bad.p + q0, c->q_norm.p + q0, s));
+                                               g.unit_rows, c->q_bad.p + q0, c->q_norm.p + q0, s));
         size_t slot = 0;
         prof_begin(c, s, slot);
         HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
@@ -616,7 +617,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.id_base = c->id_base;
         a.strip_tiles = g.strip_tiles;
         a.wm = g.wm;
-        a.wave_rows = g.wave_rows;
+        a.wave_rows = g.cand_layout;
         a.euclid = euclid;
         a.q_norm = c->q_norm.p + q0;
         a.gamma = mfma_gamma(g.k_pad);
@@ -667,7 +668,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     if (!d_queries || !d_hits)
         fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
     // Cosine on every prefilter kernel; Euclidean (the reference's metric or its Simd twin) on the 256 x 256 ones
-    const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && c->mfma_variant <= 1u);
+    const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && (c->mfma_variant <= 1u || c->mfma_variant == 4u));
     const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok && c->mfma_backoff > 0) {
@@ -778,7 +779,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
-        c->mfma_variant = (uint32_t)std::min<uint64_t>(3, env_u64("VFSX_MFMA_VARIANT", 1));
+        c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)

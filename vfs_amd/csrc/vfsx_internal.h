@@ -88,6 +88,9 @@ struct MfmaGeometry {
     uint32_t wm;         // waves along M (2 or 4)
     uint32_t wave_rows;  // rows per wave tile (64 or 128): workgroup tile = wave_rows*wm rows
     uint32_t tile_queries; // queries per workgroup tile (128 or 256)
+    uint32_t unit_rows;  // rows per 1 KiB mirror unit: 32 (32x32x16 MFMA operands) or 16 (16x16x32)
+    uint32_t lists_per_strip;
+    uint32_t cand_layout; // how a candidate's low mantissa bits + list map back to a row (cand_row)
     uint32_t n_rowtiles; // ceil(n_rows / (wave_rows*wm))
     uint32_t strip_tiles; // row tiles per strip (1..32)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
@@ -117,9 +120,9 @@ struct MfmaRescoreArgs {
 };
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
-                              uint32_t n_rowgroups, int *bad_flag, hipStream_t s);
+                              uint32_t n_rowgroups, uint32_t unit_rows, int *bad_flag, hipStream_t s);
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                  int *q_bad, float *q_norm, hipStream_t s);
+                                  uint32_t unit_rows, int *q_bad, float *q_norm, hipStream_t s);
 // out[n_pad] float2 = (b, b^2 (1 - gamma)), zero beyond n_rows
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
                                      hipStream_t s);

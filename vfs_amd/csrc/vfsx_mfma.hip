@@ -57,7 +57,7 @@ template <int DTYPE>
 __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
                                    const float *__restrict__ lut, uint4 *__restrict__ mirror, uint32_t n_rows,
                                    uint32_t dim, uint32_t d_chunks, uint32_t KS, uint64_t total_units,
-                                   int *__restrict__ bad_flag)
+                                   int *__restrict__ bad_flag, uint32_t unit_rows)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t unit = t >> 6;
@@ -65,14 +65,16 @@ __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float
         return;
     const uint32_t lane = (uint32_t)(t & 63u);
     const uint32_t g = (uint32_t)(unit / KS), s = (uint32_t)(unit % KS);
-    const uint32_t row = g * 32u + (lane & 31u);
-    const uint32_t k0 = s * 16u + (lane >> 5) * 8u;
+    // unit = unit_rows x (512 / unit_rows) bf16: 32 x 16 (v_mfma_f32_32x32x16_bf16 operands) or
+    // 16 x 32 (v_mfma_f32_16x16x32_bf16); lane l <-> row l % unit_rows, 8 consecutive k from 8 (l / unit_rows)
+    const uint32_t row = g * unit_rows + (lane % unit_rows);
+    const uint32_t k0 = s * (512u / unit_rows) + (lane / unit_rows) * 8u;
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < n_rows) {
         const float n2 = row_norms[row];
         const bool ok = (n2 > 0.0f) && (n2 < __uint_as_float(0x7f800000u));
         if (!ok) {
-            if (s == 0 && (lane >> 5) == 0)
+            if (s == 0 && lane < unit_rows)
                 atomicOr(bad_flag, 1);
         } else {
             const uint8_t *base = (const uint8_t *)(corpus + (size_t)(row >> 6) * d_chunks * 64u + (row & 63u));
@@ -112,7 +114,7 @@ __global__ void mfma_rownorm_pairs_kernel(const float *__restrict__ row_norms, u
 // ---- query prep: one wave per query -------------------------------------------------------
 __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
                                        uint16_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad,
-                                       float *__restrict__ q_norm)
+                                       float *__restrict__ q_norm, uint32_t unit_rows)
 {
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -132,8 +134,9 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
     if (!ok)
         return; // mirror stays zero (memset by the host)
     for (uint32_t k = lane; k < dim; k += 64) {
-        const uint32_t unit = (q >> 5) * KS + (k >> 4);
-        const uint32_t l2 = (q & 31u) + 32u * ((k & 15u) >> 3);
+        const uint32_t unit_k = 512u / unit_rows; // see mfma_mirror_kernel
+        const uint32_t unit = (q / unit_rows) * KS + (k / unit_k);
+        const uint32_t l2 = (q % unit_rows) + unit_rows * ((k % unit_k) >> 3);
         q_mirror[((size_t)unit * 64u + l2) * 8u + (k & 7u)] = (uint16_t)f32_to_bf16_rne(src[k] / n1);
     }
 }
@@ -599,6 +602,214 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     }
 }
 
+// ---- prefilter GEMM on v_mfma_f32_16x16x32_bf16 (variant 4) ------------------------------------------
+// Same 256 x 256 tile, 8 waves as 2 (M) x 4 (N), 128 rows x 64 queries per wave, BK = 64 in a 2-slot
+// ring, same staging / barrier protocol and bookkeeping as mfma_prefilter256_kernel -- but the
+// contraction runs on the 16x16x32 MFMA shape (32 per 32-wide k-slice instead of 8 per 16-wide one; the
+// guide measures it ~1.15x the FLOP/s of 32x32x16 at equal cycles because the chip holds a higher clock
+// on it).  The mirrors are then laid out in 16-row x 32-k units (lane l <-> row l & 15, k = 8 (l >> 4)..).
+// C/D: column (query) = lane & 15, row = 4 (lane >> 4) + reg.  A lane therefore sees 32 rows of a tile
+// (8 mi x 4 regs) for each of its 4 query columns; candidate lists: list = strip * 8 + wave_m * 4 +
+// (lane >> 4), up to 32 tiles (8192 rows) per strip, index = tile-in-strip (5 bits) | mi (3) | reg (2).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void mfma_prefilter256x_kernel(const uint4 *__restrict__ A,
+                                                                 const uint4 *__restrict__ B,
+                                                                 float *__restrict__ cand, uint32_t n_rows,
+                                                                 uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
+                                                                 uint32_t nq, uint32_t n_lists, uint32_t strip_tiles,
+                                                                 const float2 *__restrict__ rn2,
+                                                                 const float *__restrict__ q_norm, float eps_e)
+{
+    constexpr uint32_t TROWS = 256u, TQ = 256u;
+    constexpr uint32_t KU = 2u;                         // 32-wide k-slices per K-step (BK = 64)
+    constexpr uint32_t A_UNITS = 16u * KU, UNITS = 32u * KU; // 16-row units: 16 row groups + 16 query groups
+    constexpr uint32_t G = UNITS / 8u;                  // 8 pieces per wave and stage
+    __shared__ __align__(16) uint4 lds_s0[UNITS * 64];
+    __shared__ __align__(16) uint4 lds_s1[UNITS * 64];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
+    const uint32_t wave_m = wave >> 2, wave_n = wave & 3u;
+
+    // XCD-aware mapping: see mfma_prefilter_kernel
+    const uint32_t total = gridDim.x;
+    const uint32_t id = blockIdx.x, xcd = id & 7u;
+    uint32_t strip, qtile;
+    if ((n_qtiles & 7u) == 0u) {
+        const uint32_t qpx = n_qtiles >> 3, within = id >> 3;
+        strip = within / qpx;
+        qtile = xcd * qpx + within % qpx;
+    } else {
+        const uint32_t q8 = total >> 3, r8 = total & 7u;
+        const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
+        strip = t / n_qtiles;
+        qtile = t % n_qtiles;
+    }
+    const uint32_t tile0 = strip * strip_tiles;
+    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
+    const uint32_t KT = KS / KU;
+    const uint32_t n_it = ntiles * KT;
+
+    // staging and bookkeeping: as in mfma_prefilter256_kernel (waves 0-3: row units, 4-7: query units)
+    const bool a_wave = wave < 4u;
+    const uint32_t lane16 = lane * 16u;
+    uint32_t pc_soff[G], pc_lds[G];
+#pragma unroll
+    for (uint32_t u = 0; u < G; ++u) {
+        const uint32_t unit = (wave & 3u) * G + u; // 0 .. 31
+        const uint32_t grp = unit / KU, ks = unit % KU;
+        pc_soff[u] = (grp * KS + ks) * 1024u;
+        pc_lds[u] = ((a_wave ? 0u : A_UNITS) + unit) * 1024u;
+    }
+    const uint32_t tile_bytes = 16u * KS * 1024u; // one 256-row tile of the mirror
+    uintptr_t nx_base = a_wave ? (uintptr_t)A + (uintptr_t)tile0 * tile_bytes : (uintptr_t)B + (uintptr_t)qtile * tile_bytes;
+    uint32_t nx_idx = 0, nx_koff = 0;
+    auto next_rsrc = [&]() -> __amdgpu_buffer_rsrc_t {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, 0xffffffff, 0x00020000);
+    };
+    auto advance = [&]() {
+        if (nx_idx + 1u < n_it) {
+            ++nx_idx;
+            nx_koff += KU * 1024u;
+            if (nx_koff == KS * 1024u) {
+                nx_koff = 0;
+                if (a_wave)
+                    nx_base += tile_bytes;
+            }
+        }
+    };
+    auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t koff, uint32_t slot_base, uint32_t u) {
+        uint32_t a = slot_base + pc_lds[u]; // laundered: see glds16_untracked
+        asm volatile("" : "+s"(a));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
+                                                 (int)lane16, (int)(pc_soff[u] + koff), 0, 0);
+    };
+    auto lds_addr = [&](uint4 *p) -> uint32_t {
+        return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)p;
+    };
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const float ninf = __uint_as_float(0xff800000u);
+    float m1[4], m2[4], m3[4], cq[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        m1[ni] = m2[ni] = m3[ni] = ninf;
+        cq[ni] = 0.0f;
+        if (MODE == 1) {
+            const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 16u + (lane & 15u);
+            cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
+        }
+    }
+    uint32_t keep_mask = ~kIdxMask;
+    asm volatile("" : "+v"(keep_mask));
+    uint32_t cur_kt = 0, cur_ts = 0;
+
+    auto fold_tile = [&](auto ragged_c, uint32_t ts, uint32_t tile_row0) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            // accumulator registers 0..3 of tile mi are 4 consecutive rows
+            const uint32_t row4 = tile_row0 + wave_m * 128u + (uint32_t)mi * 16u + 4u * (lane >> 4);
+            float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) {
+                const float4 p0 = *(const float4 *)(rn2 + row4);
+                const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
+                bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
+                bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t idx =
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 5) | ((uint32_t)mi << 2) | (uint32_t)r));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    float v = acc[mi][ni][r];
+                    if (MODE == 1)
+                        v = cq[ni] * (bn[r] * (v + eps_e)) - bs[r];
+                    float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
+                    if (RAGGED && row4 + (uint32_t)r >= n_rows)
+                        sp = ninf;
+                    m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+                    m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
+                    asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
+                    acc[mi][ni][r] = 0.0f;
+                }
+            }
+        }
+    };
+
+    auto kstep = [&](uint4 *rd_slot, uint4 *wr_slot) __attribute__((always_inline)) {
+        const uint4 *rd = rd_slot;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // 2-slot ring: the stage for this K-step has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const __amdgpu_buffer_rsrc_t rsrc_n = next_rsrc();
+        const uint32_t koff_n = nx_koff;
+        const uint32_t wr = lds_addr(wr_slot);
+        advance();
+#pragma unroll
+        for (uint32_t ks = 0; ks < KU; ++ks) {
+            bf16x8 a[8], b[4];
+#pragma unroll
+            for (uint32_t mi = 0; mi < 8; ++mi)
+                a[mi] = as_bf16x8(rd[((wave_m * 8u + mi) * KU + ks) * 64u + lane]);
+#pragma unroll
+            for (uint32_t ni = 0; ni < 4; ++ni)
+                b[ni] = as_bf16x8(rd[(A_UNITS + (wave_n * 4u + ni) * KU + ks) * 64u + lane]);
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) // the next stage's 8 pieces, 4 per k-slice
+                stage_piece(rsrc_n, koff_n, wr, ks * 4u + u);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (++cur_kt == KT) {
+            const uint32_t ts = cur_ts;
+            cur_kt = 0;
+            ++cur_ts;
+            const uint32_t tile_row0 = (tile0 + ts) * TROWS;
+            if (tile_row0 + TROWS > n_rows)
+                fold_tile(std::true_type{}, ts, tile_row0);
+            else
+                fold_tile(std::false_type{}, ts, tile_row0);
+        }
+    };
+
+    { // stage 0 into slot 0
+        const __amdgpu_buffer_rsrc_t rsrc = next_rsrc();
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u)
+            stage_piece(rsrc, nx_koff, lds_addr(lds_s0), u);
+        advance();
+    }
+    // n_it is even (K % 128 == 0): straight-line rounds over the two slots
+    for (uint32_t it = 0; it < n_it; it += 2) {
+        kstep(lds_s0, lds_s1);
+        kstep(lds_s1, lds_s0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the redundant tail stage must land before the LDS is released
+
+    const uint32_t list = strip * 8u + wave_m * 4u + (lane >> 4);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 16u + (lane & 15u);
+        if (q < nq) {
+            cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
+            cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
+            cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+        }
+    }
+}
+
 // ---- select: kp best approximate scores of one query ------------------------------------------
 // composite = key(-score) << 32 | list ; smaller = better.  One workgroup per query.
 template <typename TopK, int WAVES>
@@ -656,6 +867,13 @@ __device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32
     const uint32_t list = (uint32_t)comp;
     score = -key_dist((uint32_t)(comp >> 32));
     const uint32_t idx = __float_as_uint(score) & kIdxMask;
+    if (wave_rows == 129u) {
+        // mfma_prefilter256x_kernel (16x16x32 MFMA): idx = ts (5 bits) | mi (3) | reg (2);
+        // list = strip * 8 + wave_m * 4 + (lane >> 4); row = tile * 256 + wave_m * 128 + mi * 16 + 4 (lane >> 4) + reg
+        const uint32_t ts = idx >> 5, mi = (idx >> 2) & 7u, r = idx & 3u;
+        const uint32_t strip = list >> 3, wave_m = (list >> 2) & 1u, g4 = list & 3u;
+        return (strip * strip_tiles + ts) * 256u + wave_m * 128u + mi * 16u + 4u * g4 + r;
+    }
     const uint32_t mi_bits = wave_rows == 128u ? 2u : 1u;
     const uint32_t ts = idx >> (4u + mi_bits), mi = (idx >> 4) & ((1u << mi_bits) - 1u), r = idx & 15u;
     const uint32_t strip = list / (2u * wm), wave_m = (list % (2u * wm)) >> 1, half = list & 1u;
@@ -837,27 +1055,27 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
 
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
-                              uint32_t n_rowgroups, int *bad_flag, hipStream_t s)
+                              uint32_t n_rowgroups, uint32_t unit_rows, int *bad_flag, hipStream_t s)
 {
-    const uint64_t total_units = (uint64_t)n_rowgroups * KS; // 32-row groups, rows padded to a multiple of 256
+    const uint64_t total_units = (uint64_t)n_rowgroups * KS; // unit_rows-row groups, rows padded to a multiple of 256
     const uint64_t threads = total_units * 64u;
     const uint64_t blocks = (threads + 255) / 256;
     if (blocks > 0x7fffffffull)
         return hipErrorInvalidValue;
     if (dtype == VFSX_I8)
         hipLaunchKernelGGL((mfma_mirror_kernel<VFSX_I8>), dim3((uint32_t)blocks), dim3(256), 0, s, corpus, row_norms,
-                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag);
+                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag, unit_rows);
     else
         hipLaunchKernelGGL((mfma_mirror_kernel<VFSX_F32>), dim3((uint32_t)blocks), dim3(256), 0, s, corpus, row_norms,
-                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag);
+                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag, unit_rows);
     return hipGetLastError();
 }
 
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                  int *q_bad, float *q_norm, hipStream_t s)
+                                  uint32_t unit_rows, int *q_bad, float *q_norm, hipStream_t s)
 {
     hipLaunchKernelGGL(mfma_query_prep_kernel, dim3(nq), dim3(64), 0, s, d_queries, nq, dim, (uint16_t *)q_mirror, KS,
-                       q_bad, q_norm);
+                       q_bad, q_norm, unit_rows);
     return hipGetLastError();
 }
 
@@ -878,8 +1096,17 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
     const dim3 grid(g.n_strips * n_qtiles);
     const uint4 *qm = (const uint4 *)q_mirror;
     const float2 *rn = (const float2 *)rn2;
-    if (euclid && g.variant > 1u)
+    if (euclid && g.tile_queries != 256u)
         return hipErrorInvalidValue;
+    if (g.variant == 4u) {
+        if (euclid)
+            hipLaunchKernelGGL((mfma_prefilter256x_kernel<1>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,
+                               g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
+        else
+            hipLaunchKernelGGL((mfma_prefilter256x_kernel<0>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,
+                               g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
+        return hipGetLastError();
+    }
 #define VFSX_PF256(KU, NS, MODE)                                                                                   \
     hipLaunchKernelGGL((mfma_prefilter256_kernel<KU, NS, MODE>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,   \
                        g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e)
@@ -950,23 +1177,28 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
 MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t variant)
 {
     MfmaGeometry g;
-    g.variant = variant > 3u ? 0u : variant;
-    g.wave_rows = g.variant <= 1u ? 128u : 64u;
+    g.variant = variant > 4u ? 1u : variant;
+    const bool x16 = g.variant == 4u;   // 16x16x32 MFMA, 16-row units
+    const bool t256 = g.variant <= 1u || x16;
+    g.wave_rows = t256 ? 128u : 64u;
     g.wm = g.variant == 2u ? 4u : 2u; // waves along M
-    g.tile_queries = g.variant <= 1u ? 256u : 128u;
+    g.tile_queries = t256 ? 256u : 128u;
+    g.unit_rows = x16 ? 16u : 32u;
+    g.lists_per_strip = x16 ? 8u : 2u * g.wm;
+    g.cand_layout = x16 ? 129u : g.wave_rows;
     const uint32_t tile_rows = g.wave_rows * g.wm;
     // the 256 x 256 kernels run whole ring rounds only: K-steps per tile % ring depth == 0 <=> K % 128 == 0
-    const uint32_t k_mult = g.variant <= 1u ? 128u : 64u;
+    const uint32_t k_mult = t256 ? 128u : 64u;
     g.k_pad = (dim + k_mult - 1u) / k_mult * k_mult;
-    g.KS = g.k_pad / 16u;
+    g.KS = g.k_pad / (512u / g.unit_rows);
     g.n_rowtiles = (n_rows + tile_rows - 1) / tile_rows;
     // aim for >= ~4096 candidate lists per query so that three rows above the safety margin rarely share
-    // one (small corpora get short strips -- and more workgroups); at most 4096 rows per strip and
-    // 32 tiles (5 index bits)
-    const uint32_t max_tiles = std::min<uint32_t>(kMaxStripTiles, 4096u / tile_rows);
-    g.strip_tiles = std::min<uint32_t>(max_tiles, std::max<uint32_t>(1u, (n_rows / tile_rows) * (2u * g.wm) / 4096u));
+    // one (small corpora get short strips -- and more workgroups); a list holds at most 1024 rows (10 index
+    // bits): 4096 rows per strip with 4 or 8 lists (32x32 MFMA), 8192 rows with 8 lists (16x16 MFMA)
+    const uint32_t max_tiles = std::min<uint32_t>(kMaxStripTiles, (x16 ? 8192u : 4096u) / tile_rows);
+    g.strip_tiles = std::min<uint32_t>(max_tiles, std::max<uint32_t>(1u, (n_rows / tile_rows) * g.lists_per_strip / 4096u));
     g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
-    g.n_lists = g.n_strips * 2u * g.wm;
+    g.n_lists = g.n_strips * g.lists_per_strip;
     g.mirror_bytes = (size_t)((n_rows + 255u) / 256u) * 256u * g.k_pad * 2u; // rows padded for either tile
     return g;
 }
