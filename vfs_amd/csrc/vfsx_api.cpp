@@ -147,6 +147,7 @@ struct vfsx_corpus {
     uint64_t nq_per_pass_max = 8;
     int nt_override = 2;     // 2 = auto
     int pipe_override = 2;   // 2 = auto
+    bool balanced_grid = true; // VFSX_BALANCED_GRID=0: always the full grid (A/B measurements)
 
     // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
     struct RowMeta {
@@ -452,6 +453,16 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
         }
     }
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + 3u) / 4u, c->max_blocks);
+    if (grid_x) {
+        // Even shares when a wave only gets a few row-blocks: with r = ceil(row-blocks / waves), the
+        // smallest grid that still covers the corpus gives (almost) every wave exactly r of them, so the
+        // waves finish together instead of 1 - frac(r) of them idling through the last round (C2:
+        // 15625 row-blocks, 1024 -> 977 workgroups, 455 -> 447 us).  With many row-blocks per wave the
+        // imbalance is noise and the full grid is (slightly) better.
+        const uint32_t per_wave = (n_rowblocks + 4u * grid_x - 1u) / (4u * grid_x);
+        if (per_wave <= 16u && c->balanced_grid)
+            grid_x = (n_rowblocks + 4u * per_wave - 1u) / (4u * per_wave);
+    }
     // queries per launch: bounded by gridDim.y and by a 256 MiB list workspace
     uint32_t q_per_launch = nq;
     if (grid_x) {
@@ -778,6 +789,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nt_override = (int)env_u64("VFSX_SCAN_NT", 2);
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
+        c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
         c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
