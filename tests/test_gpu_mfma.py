@@ -222,3 +222,23 @@ def test_mfma_backs_off_when_the_check_keeps_failing(oracle):
         oi, od, _ = oracle.topk_scan(rows, queries[3], 1, 10)
         assert (ids[3] == oi).all() and (bits(dist[3]) == bits(od)).all()
     c.close()
+
+
+def test_mfma_scattered_fallbacks_are_compacted(oracle):
+    """Every other query sits inside a near-duplicate cluster (fails the check), the rest are ordinary:
+    the flagged ones are gathered into one exact batch and their hits scattered back in place."""
+    import vfs_amd
+    rng = np.random.default_rng(33)
+    n, d = 40000, 64
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    center = rng.uniform(-1, 1, d).astype(np.float32)
+    rows[5000:9000] = (center + rng.normal(0, 1e-4, (4000, d))).astype(np.float32)
+    queries = rng.uniform(-1, 1, (140, d)).astype(np.float32)
+    queries[::2] = (center + rng.normal(0, 1e-4, (70, d))).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    fb = _compare(c, queries, 10, oracle, rows, metric=1)
+    assert 0 < fb < 140
+    fb = _compare(c, queries, 10, oracle, rows, metric=0)
+    assert 0 < fb < 140
+    c.close()

@@ -166,6 +166,9 @@ struct vfsx_corpus {
     float *d_rn2 = nullptr;      // [mirror rows padded] float2 (b, b^2 (1 - gamma)) for Euclidean batches
     size_t rn2_rows = 0;
     DeviceBuf<float> q_norm;
+    DeviceBuf<uint32_t> fb_idx;  // exact fallback of flagged queries: their indices, compacted copies, hits
+    DeviceBuf<float> fb_queries;
+    DeviceBuf<vfsx_hit> fb_hits;
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 64;
     uint32_t mfma_variant = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
@@ -648,23 +651,33 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
             c->mfma_backoff_next = 0;
         }
     }
-    // exact scan for the queries the check flagged, in contiguous runs (not part of the
-    // profiled kernel: the event brackets on this path time the prefilter GEMM only)
-    const bool prof_saved = c->profiling;
-    c->profiling = false;
-    for (uint32_t q = 0; q < nq;) {
-        if (!c->h_flags[q]) {
-            ++q;
-            continue;
+    // Exact scan for the queries the check flagged (not part of the profiled kernel: the event brackets
+    // on this path time the prefilter GEMM only).  They are compacted into one batch first, so that they
+    // share corpus passes (8 queries per pass) wherever they sat in the caller's batch.
+    std::vector<uint32_t> flagged;
+    for (uint32_t q = 0; q < nq; ++q)
+        if (c->h_flags[q])
+            flagged.push_back(q);
+    if (!flagged.empty()) {
+        const bool prof_saved = c->profiling;
+        c->profiling = false;
+        const uint32_t nf = (uint32_t)flagged.size();
+        if (nf == nq) {
+            exact_search_device(c, d_queries, nq, k, metric, d_hits, s);
+        } else {
+            c->fb_idx.reserve(nf);
+            c->fb_queries.reserve((size_t)nf * c->dim);
+            c->fb_hits.reserve((size_t)nf * k);
+            HIP_CHECK(hipMemcpyAsync(c->fb_idx.p, flagged.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            HIP_CHECK(vfsx::launch_move_records(d_queries, c->fb_queries.p, c->fb_idx.p, nf, c->dim, 0, s));
+            exact_search_device(c, c->fb_queries.p, nf, k, metric, c->fb_hits.p, s);
+            HIP_CHECK(vfsx::launch_move_records(c->fb_hits.p, d_hits, c->fb_idx.p, nf,
+                                                (uint32_t)(k * sizeof(vfsx_hit) / sizeof(uint32_t)), 1, s));
+            HIP_CHECK(hipStreamSynchronize(s)); // `flagged` (pageable host memory) must outlive the H2D copy
         }
-        uint32_t e = q;
-        while (e < nq && c->h_flags[e])
-            ++e;
-        exact_search_device(c, d_queries + (size_t)q * c->dim, e - q, k, metric, d_hits + (size_t)q * k, s);
-        c->mfma_fallbacks += e - q;
-        q = e;
+        c->mfma_fallbacks += nf;
+        c->profiling = prof_saved;
     }
-    c->profiling = prof_saved;
 }
 
 void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
@@ -834,6 +847,9 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->q_mirror.release();
     c->q_bad.release();
     c->q_norm.release();
+    c->fb_idx.release();
+    c->fb_queries.release();
+    c->fb_hits.release();
     c->q_flags.release();
     c->cand.release();
     c->sel.release();

@@ -72,6 +72,9 @@ hipError_t launch_get_rows(int dtype, const uint4 *corpus, uint32_t dim, uint32_
                            void *d_out, hipStream_t s);
 hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
                              vfsx_hit *d_out, hipStream_t s);
+// n records of `words` dwords: gather dst[i] = src[idx[i]] (scatter = 0) or scatter dst[idx[i]] = src[i]
+hipError_t launch_move_records(const void *src, void *dst, const uint32_t *d_idx, uint32_t n, uint32_t words,
+                               int scatter, hipStream_t s);
 
 // ---- integer-domain Euclidean on int8 corpora (vfsx_i8dom.hip; VFSX_EUCLIDEAN_I8DOMAIN) ----------
 // d_qw[nq][qw_stride]: n_words packed quantized dwords, then sum qi^2; qw_stride % 4 == 0

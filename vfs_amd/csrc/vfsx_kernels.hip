@@ -505,6 +505,18 @@ __global__ __launch_bounds__(kBlock) void merge_hits_kernel(const vfsx_hit *__re
     }
 }
 
+// ---- compact / scatter whole records by index (dwords) ------------------------------------------
+// gather: dst[i] = src[idx[i]]; scatter: dst[idx[i]] = src[i]; one workgroup per record
+__global__ void move_records_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                    const uint32_t *__restrict__ idx, uint32_t words, int scatter)
+{
+    const uint32_t i = blockIdx.x, j = idx[i];
+    const uint32_t *s = src + (size_t)(scatter ? i : j) * words;
+    uint32_t *d = dst + (size_t)(scatter ? j : i) * words;
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x)
+        d[w] = s[w];
+}
+
 } // namespace
 
 // ---- launchers --------------------------------------------------------------------------------------
@@ -687,6 +699,16 @@ hipError_t launch_get_rows(int dtype, const uint4 *corpus, uint32_t dim, uint32_
         hipLaunchKernelGGL((get_rows_kernel<VFSX_F32, 1>), grid, block, 0, s, corpus, dim, d_chunks, d_lut,
                            d_rows, n, d_out);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_move_records(const void *src, void *dst, const uint32_t *d_idx, uint32_t n, uint32_t words,
+                               int scatter, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(move_records_kernel, dim3(n), dim3(256), 0, s, (const uint32_t *)src, (uint32_t *)dst, d_idx,
+                       words, scatter);
     return hipGetLastError();
 }
 
