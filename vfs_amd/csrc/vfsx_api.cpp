@@ -592,7 +592,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     uint32_t q_round = (uint32_t)std::max<uint64_t>(256, std::min<uint64_t>(nq, (1ull << 30) / per_q) / 256u * 256u);
     q_round = std::min<uint32_t>(q_round, (nq + 255u) / 256u * 256u);
     c->cand.reserve((size_t)q_round * 3u * g.n_lists);
-    c->sel.reserve((size_t)q_round * kp);
+    c->sel.reserve((size_t)q_round * 256u); // kp in the first pass, 256 in the second
     c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
     c->q_bad.reserve(nq);
     c->q_norm.reserve(nq);
@@ -610,7 +610,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
                                               c->d_rn2, c->q_norm.p + q0, eps_e, s));
         prof_end(c, s, slot);
-        HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, s));
+        HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, nullptr, s));
         vfsx::MfmaRescoreArgs a{};
         a.corpus = c->d_corpus;
         a.row_norms = c->d_norms;
@@ -636,6 +636,16 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.q_norm = c->q_norm.p + q0;
         a.gamma = mfma_gamma(g.k_pad);
         HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
+        // second pass, entirely on the device: a query that failed because more than kp rows sit above its
+        // safety margin gets the widest candidate set the re-score kernel takes (256) and is decided
+        // again; queries that passed exit at once.  (A list with three entries above the margin stays
+        // flagged: only the exact scan can look inside it.)
+        if (kp < 256u) {
+            HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, 256u, a.flags, s));
+            a.kp = 256u;
+            a.only_flagged = 1;
+            HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
+        }
     }
     HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));

@@ -120,6 +120,7 @@ struct MfmaRescoreArgs {
     int euclid;           // 0 = Cosine, 1 = Euclidean (see vfsx_mfma.hip)
     const float *q_norm;  // [nq] the scalar each query mirror row was divided by
     float gamma;          // relative f32 error allowance of the Euclidean check
+    int only_flagged;     // != 0: second pass, only queries whose flags[q] is set (they are re-decided)
 };
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
                               uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
@@ -132,8 +133,9 @@ hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, ui
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
                                  const float *q_norm, float eps_e, hipStream_t s);
+// only_flagged != nullptr: skip queries whose flag is 0
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
-                              hipStream_t s);
+                              const int *only_flagged, hipStream_t s);
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);
 
 // host helpers shared with the host merge

@@ -815,8 +815,10 @@ __global__ __launch_bounds__(512) void mfma_prefilter256x_kernel(const uint4 *__
 template <typename TopK, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__restrict__ cand,
                                                                  uint64_t *__restrict__ sel, uint32_t n_lists,
-                                                                 uint32_t kp)
+                                                                 uint32_t kp, const int *__restrict__ only_flagged)
 {
+    if (only_flagged && only_flagged[blockIdx.x] == 0) // second, wider pass: flagged queries only
+        return;
     constexpr uint32_t BLOCK = 64u * WAVES;
     extern __shared__ __align__(16) uint64_t dyn_lds[];
     const uint32_t lane = lane_id();
@@ -887,8 +889,11 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, float eps, uint64_t row_base, uint64_t id_base,
-    uint32_t strip_tiles, uint32_t wm, uint32_t wave_rows, const float *__restrict__ q_norm, float gamma)
+    uint32_t strip_tiles, uint32_t wm, uint32_t wave_rows, const float *__restrict__ q_norm, float gamma,
+    int only_flagged)
 {
+    if (only_flagged && flags[blockIdx.x] == 0) // second, wider pass: flagged queries only (uniform exit)
+        return;
     constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
     extern __shared__ __align__(16) uint64_t dyn_lds[]; // [4][max(k,64)]
     __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
@@ -1131,20 +1136,20 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 }
 
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
-                              hipStream_t s)
+                              const int *only_flagged, hipStream_t s)
 {
     constexpr int W = 16;
     const uint32_t list_stride = kp > 64u ? kp : 64u;
     const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
     if (kp <= kMaxRegisterK)
         hipLaunchKernelGGL((mfma_select_kernel<WaveTopKReg, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
-                           kp);
+                           kp, only_flagged);
     else if (kp <= 128u)
         hipLaunchKernelGGL((mfma_select_kernel<WaveTopKReg2, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
-                           kp);
+                           kp, only_flagged);
     else
         hipLaunchKernelGGL((mfma_select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, cand, sel, n_lists,
-                           kp);
+                           kp, only_flagged);
     return hipGetLastError();
 }
 
@@ -1156,7 +1161,7 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,           \
                        a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks,    \
                        a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows,         \
-                       a.q_norm, a.gamma)
+                       a.q_norm, a.gamma, a.only_flagged)
     if (dtype == VFSX_I8) {
         if (a.euclid)
             VFSX_RESCORE(VFSX_I8, VFSX_EUCLIDEAN);
