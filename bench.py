@@ -264,7 +264,7 @@ def main() -> int:
 
 def pmc_traffic(workload, rows):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/rNN/traffic.json, written by tools_summarize_profile.py); None if
+    command (profiles/rNN/traffic.json, written by tools/summarize_profile.py); None if
     there is no profile for this workload/size.  PMC counters cannot be read in-process."""
     import glob
     if rows != WORKLOADS[workload][0]:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ingest throughput of the pinned, double-buffered H2D pipeline (vfsx_corpus_append*)
-and of the log loader (vfsx_corpus_load_log).  Run on the GPU box: python tools_ingest_bench.py"""
+and of the log loader (vfsx_corpus_load_log).  Run on the GPU box: python tools/ingest_bench.py"""
 import os
 import sys
 import tempfile
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vfs_amd
 from vfs_amd import vfslog
 

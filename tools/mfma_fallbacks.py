@@ -1,5 +1,6 @@
 import numpy as np, sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vfs_amd
 rng = np.random.default_rng(1)
 for (n, d, scale_rows) in [(40000,128,False),(200000,768,False),(60000,96,True),(1000000,256,False),(1000000,256,True)]:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/prof_<tag>/ (tools_profile.sh) into profiles/r01/<tag>_summary.{md,json}.
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/r01/<tag>_summary.{md,json}.
 HBM traffic per launch follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in
 KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streaming reads, so the
 read side is doubled.  Separate --pmc passes, one counter each."""
@@ -39,7 +39,7 @@ bench = json.loads(bench_line)
 out = {"bench_line_under_profiler": bench, "kernels": []}
 md = [f"# rocprofv3 summary `{tag}` ({rnd})", "",
       "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline "
-      f"--workload {tag}` (steps/warmup as in tools_profile.sh); PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (one run each).",
+      f"--workload {tag}` (steps/warmup as in tools/profile.sh); PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (one run each).",
       "", "| kernel | calls | avg µs | % time | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM bytes/launch (2·fetch+write) |",
       "|---|---|---|---|---|---|---|"]
 for r in rows:
