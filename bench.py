@@ -300,6 +300,9 @@ def cpu_baseline(args, rows, dim, quantize, metric, k):
            "sample": f"{len(qs)} queries x first {n} rows of the same synthetic corpus "
                      f"({dt:.1f} s of CPU), rows/s scaled to the full {rows}-row corpus",
            "rows_per_s": round(rows_per_s, 1)}
+    if metric in (2, 3) and dim not in (2, 4, 8, 16, 32, 64):
+        out["note"] = ("the reference's Simd* methods panic unless d is one of 2..64 (rank.rs:31,303,307); this is the "
+                       "scalar-order port, which Simd* equals bit for bit wherever it runs (ordered reduce_sum)")
     # context only: a 64-lane-chunked, vectorised restatement of the
     # reference's core::simd path (oracle/cpu_context.c; different summation order, so NOT the
     # parity arithmetic), on one core and on this process's cores (capped at 16)
