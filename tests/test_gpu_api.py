@@ -196,3 +196,17 @@ def test_vfsx_init_counts_devices():
     n = lib.vfsx_device_count()
     assert n >= 1 and lib.vfsx_init(1) == _lib.OK and lib.vfsx_init(n) == _lib.OK
     assert lib.vfsx_init(n + 1) == _lib.ERR_NO_DEVICE
+
+
+def test_rccl_collective_and_device_merge_single_rank():
+    """The N > 1 data path (one RCCL all_gather_into_tensor of the hit lists + vfsx_merge_hits_device) on
+    the real `nccl` backend, with the one GPU this box has: world size 1, collective forced.  Run in a
+    child process so the process group does not leak into the test session."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "rccl_world1_check.py")], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "OK rccl" in r.stdout

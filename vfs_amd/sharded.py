@@ -41,7 +41,8 @@ def merge_hits_host(gathered: np.ndarray, k: int) -> np.ndarray:
     return out
 
 
-def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[int] = None):
+def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[int] = None,
+                       force_collective: bool = False):
     """local_hits: torch int32 tensor [nq, k, 6] (a view of vfsx_hit[nq*k]) on this
     rank's device (cuda -> RCCL all-gather + device merge; cpu -> gloo + host merge).
     Returns the merged [nq, k, 6] tensor (same device), identical on every rank."""
@@ -50,8 +51,8 @@ def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[in
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     nq = local_hits.shape[0]
-    if world == 1:
-        return local_hits
+    if world == 1 and not (force_collective and dist.is_initialized()):
+        return local_hits  # (force_collective: run the all-gather + merge anyway -- single-GPU RCCL test)
     # RCCL moves device tensors; any other backend (gloo, used for CPU tests and
     # rehearsals) gets host tensors and the host merge.
     on_device = local_hits.is_cuda and dist.get_backend(group) == "nccl"
