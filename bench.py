@@ -206,6 +206,14 @@ def main() -> int:
 
     queries = args.steps * qps_step
     qps_global = queries / elapsed
+    # which scan kernel vfsx_search_device picks (vfsx_api.cpp exact_search_device): the 16-wave int8 kernel for
+    # single-query scans of int8 stores with >= 16 row-blocks per CU and k <= 64
+    scan_kernel_name = "scan_kernel"
+    if metric == 4:
+        scan_kernel_name = "scan_i8dom_kernel"
+    elif (quantize and args.mode == "single" and k <= 64 and os.environ.get("VFSX_I8_WIDE", "1") != "0"
+          and (rows + 63) // 64 >= 16 * torch.cuda.get_device_properties(local_rank).multi_processor_count):
+        scan_kernel_name = "scan_i8w_kernel"
     value = qps_global * world  # shard scans per second (see module docstring)
     out = {
         "metric": "exact top-10 QPS (single-query scan; shard scans/s when row-sharded)",
@@ -228,7 +236,7 @@ def main() -> int:
         "hbm_gbps_aggregate": round(qps_global * algo_bytes * world / 1e9, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args.workload, rows),
-                     "kernel": "scan_i8dom_kernel" if metric == 4 else "scan_kernel", "avg_kernel_ms": round(avg_ms, 5),
+                     "kernel": scan_kernel_name, "avg_kernel_ms": round(avg_ms, 5),
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches)},
     }
     if metric == 4:

@@ -86,3 +86,32 @@ def test_random_mfma_batches_equal_the_exact_scan(seed):
         assert (cm == ce).all() and (im == ie).all(), what
         assert (_bits(dm) == _bits(de)).all(), what
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_wide_int8_scan_matches_the_oracle(oracle, seed):
+    """Single-query scans of int8 stores above 16 row-blocks per CU run the 16-wave kernel
+    (scan_i8w_kernel): ragged row counts, odd dimensions, duplicates, every reference method."""
+    import vfs_amd
+    rng = np.random.default_rng(3000 + seed)
+    d = int([7, 100, 128, 200][seed])
+    n = int(rng.integers(270_000, 330_000))
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    dup = rng.integers(0, n, 2000)
+    rows[dup] = rows[rng.integers(0, n, 2000)]
+    c = vfs_amd.Corpus(d, quantize=True)
+    c.append_f32(rows)
+    ref_rows = oracle.quantize(rows, 127.0)
+    nonzero = np.abs(ref_rows.astype(np.int32)).sum(axis=1) != 0
+    for metric in (0, 1, 2, 3):
+        if metric in (1, 3) and not nonzero.all():
+            continue
+        for k in (1, 10, 64):
+            q = rows[int(rng.integers(0, n))] if k == 10 else rng.uniform(-1, 1, d).astype(np.float32)
+            gi, gd, gc = c.search_batch(q[None, :], k, metric)
+            oi, od, _ = oracle.topk_scan(ref_rows, q, metric, k, scale=127.0)
+            what = (seed, n, d, metric, k)
+            assert int(gc[0]) == k, what
+            assert (gi[0] == oi).all(), what
+            assert (_bits(gd[0]) == _bits(od)).all(), what
+    c.close()

@@ -148,6 +148,8 @@ struct vfsx_corpus {
     int nt_override = 2;     // 2 = auto
     int pipe_override = 2;   // 2 = auto
     bool balanced_grid = true; // VFSX_BALANCED_GRID=0: always the full grid (A/B measurements)
+    uint32_t i8_wide = 1;      // VFSX_I8_WIDE: 16-wave int8 scan workgroups per CU (0 = off, default 1)
+    uint32_t n_cus = 0;
 
     // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
     struct RowMeta {
@@ -455,8 +457,13 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
             }
         }
     }
-    uint32_t grid_x = std::min<uint32_t>((n_rowblocks + 3u) / 4u, c->max_blocks);
-    if (grid_x) {
+    // single-query int8 scans of big corpora: 16-wave workgroups around one 64 KiB table (vfsx_kernels.hip)
+    const bool wide = c->dtype == VFSX_I8 && !i8dom && nq_per_pass == 1 && k <= 64u && c->i8_wide != 0 &&
+                      n_rowblocks >= 16u * c->n_cus;
+    const uint32_t wg_waves = wide ? vfsx::kWideScanWaves : 4u;
+    uint32_t grid_x = std::min<uint32_t>((n_rowblocks + wg_waves - 1u) / wg_waves,
+                                         wide ? c->n_cus * c->i8_wide : c->max_blocks);
+    if (grid_x && !wide) {
         // Even shares when a wave only gets a few row-blocks: with r = ceil(row-blocks / waves), the
         // smallest grid that still covers the corpus gives (almost) every wave exactly r of them, so the
         // waves finish together instead of 1 - frac(r) of them idling through the last round (C2:
@@ -493,6 +500,8 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
             prof_begin(c, s, slot);
             if (i8dom)
                 HIP_CHECK(vfsx::launch_scan_i8dom(a, qn, grid_x, nt != 0, c->scale, s));
+            else if (wide)
+                HIP_CHECK(vfsx::launch_scan_i8_wide(metric, a, qn, grid_x, nt != 0, c->unroll_override, s));
             else
                 HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
             prof_end(c, s, slot);
@@ -813,6 +822,8 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->nq_per_pass_max = env_u64("VFSX_SCAN_NQ", 8);
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
+        c->n_cus = (uint32_t)prop.multiProcessorCount;
+        c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
         c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

@@ -53,6 +53,10 @@ hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, ui
                        int nq_per_pass, hipStream_t s);
 // dynamic LDS the scan kernel needs (the i8 kernels add 32 KiB of static LDS for the LUT)
 size_t scan_lds_bytes(uint32_t k, int nq_per_pass, uint32_t q_stride);
+// single-query int8 scan, 16 waves per workgroup sharing a 64 KiB per-lane dequant table (k <= 64)
+constexpr uint32_t kWideScanWaves = 16;
+hipError_t launch_scan_i8_wide(int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, bool nt, int unroll,
+                               hipStream_t s);
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s);
 hipError_t launch_query_pad(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
                             uint32_t q_stride, hipStream_t s);

@@ -15,6 +15,8 @@
 //   * one list per workgroup goes to HBM; a tiny select kernel merges them.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "vfsx_device.h"
 #include "vfsx_internal.h"
 
@@ -201,6 +203,111 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
             if (q0 + n < nq)
                 top[n].store(lists + (size_t)(q0 + n) * n_lists * k + blockIdx.x, n_lists);
         }
+    }
+}
+
+// ---- single-query int8 scan, 16 waves per workgroup ------------------------------------------
+// The faithful int8 kernel above is bound by VALU issue: 5 lane-ops per element, two of them only to
+// turn a byte into an LDS address (extract, then shift-or with the lane's bank offset).  With a 64 KiB
+// table -- entry (byte, lane) at byte offset  byte * 256 + lane * 4, i.e. one private, conflict-free
+// bank column per lane -- that address is a single v_perm_b32 (byte k of the data word into address
+// byte 1, the lane offset into byte 0).  64 KiB of LDS per workgroup only pays with many waves behind
+// it: 1024 threads = 16 waves share one table, one workgroup per CU.
+constexpr int kWideWaves = 16;
+
+template <int METRIC, bool WITH_QQ>
+__device__ __forceinline__ void acc_chunk_i8w(Acc &acc, const uint4 v, const float *__restrict__ q,
+                                              const char *lut_b, uint32_t lane4)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        // address = byte << 8 | lane * 4: selector bytes (LSB first) = S1.byte0, S0.byte_b, 0, 0
+        const uint32_t off = __builtin_amdgcn_perm(w[i >> 2], lane4, 0x0c0c0000u | ((4u + (uint32_t)(i & 3)) << 8));
+        x[i] = *(const float *)(lut_b + off); // (q as f32) / scale, vector.rs:135-139
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 qv = *(const float4 *)(q + 4 * i);
+        acc_step<METRIC, WITH_QQ>(acc, qv.x, x[4 * i + 0]);
+        acc_step<METRIC, WITH_QQ>(acc, qv.y, x[4 * i + 1]);
+        acc_step<METRIC, WITH_QQ>(acc, qv.z, x[4 * i + 2]);
+        acc_step<METRIC, WITH_QQ>(acc, qv.w, x[4 * i + 3]);
+    }
+}
+
+template <int METRIC, int UNROLL, bool NT>
+__global__ __launch_bounds__(64 * kWideWaves) void scan_i8w_kernel(
+    const uint4 *__restrict__ corpus, const float *__restrict__ row_norms, const float *__restrict__ queries,
+    const float *__restrict__ lut, uint64_t *__restrict__ lists, uint32_t n_rows, uint32_t d_chunks,
+    uint32_t n_rowblocks, uint32_t q_stride, uint32_t k, uint32_t n_lists)
+{
+    __shared__ __align__(16) float lut_s[256 * 64]; // exactly 64 KiB: two workgroups fit one CU's 160 KiB
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < 256u * 64u; i += 64u * kWideWaves)
+        lut_s[i] = lut[i >> 6];
+    __syncthreads();
+    const char *lut_b = (const char *)lut_s;
+    const uint32_t lane4 = lane * 4u;
+    const float *__restrict__ q = queries + (size_t)blockIdx.y * q_stride; // wave-uniform: s_load
+
+    WaveTopKReg top;
+    top.init(k, nullptr);
+    const uint32_t n_waves = gridDim.x * kWideWaves;
+    float qn = 0.0f;
+
+    auto rowblock = [&](uint32_t blk, auto with_qq) __attribute__((always_inline)) {
+        constexpr bool QQ = decltype(with_qq)::value;
+        const uint4 *__restrict__ p = corpus + (size_t)blk * d_chunks * 64u + lane;
+        Acc acc{0.0f, 0.0f};
+        uint32_t c = 0;
+        for (; c + UNROLL <= d_chunks; c += UNROLL) {
+            uint4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                v[u] = load_chunk<NT>(p + (size_t)(c + u) * 64u);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                acc_chunk_i8w<METRIC, QQ>(acc, v[u], q + (c + u) * 16u, lut_b, lane4);
+        }
+        for (; c < d_chunks; ++c)
+            acc_chunk_i8w<METRIC, QQ>(acc, load_chunk<NT>(p + (size_t)c * 64u), q + c * 16u, lut_b, lane4);
+        if (QQ)
+            qn = f_sqrt(acc.qq); // rank.rs:296
+        const uint32_t row = blk * 64u + lane;
+        uint64_t comp = kSentinel;
+        if (row < n_rows) {
+            float dist;
+            if (METRIC == VFSX_EUCLIDEAN)
+                dist = f_sqrt(acc.a); // rank.rs:286
+            else
+                dist = f_sub(1.0f, f_div(acc.a, f_mul(qn, row_norms[row]))); // rank.rs:299
+            comp = ((uint64_t)dist_key(dist) << 32) | row;
+        }
+        top.offer(comp);
+    };
+
+    uint32_t blk = blockIdx.x * kWideWaves + wave;
+    if (METRIC == VFSX_COSINE && blk < n_rowblocks) { // first row-block also folds sum q_j^2
+        rowblock(blk, std::true_type{});
+        blk += n_waves;
+    }
+    for (; blk < n_rowblocks; blk += n_waves)
+        rowblock(blk, std::false_type{});
+
+    // fold the 16 waves' lists into wave 0's, one list per workgroup to HBM ([q][j][list]); the
+    // table is dead once every wave has left the scan, its LDS holds the 16 lists
+    __syncthreads();
+    uint64_t *dyn_lds = (uint64_t *)lut_s;
+    uint64_t *mine = dyn_lds + (size_t)wave * 64u;
+    top.spill(mine);
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < kWideWaves; ++w)
+            top.offer(lane < k ? dyn_lds[(size_t)w * 64u + lane] : kSentinel);
+        top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
     }
 }
 
@@ -588,6 +695,38 @@ hipError_t launch_scan(int dtype, int metric, const ScanArgs &a, uint32_t nq, ui
                       : launch_scan_t<VFSX_I8, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, nq_per_pass, s);
     return cosine ? launch_scan_t<VFSX_F32, VFSX_COSINE>(a, nq, grid_x, variant, nq_per_pass, s)
                   : launch_scan_t<VFSX_F32, VFSX_EUCLIDEAN>(a, nq, grid_x, variant, nq_per_pass, s);
+}
+
+// single-query int8 scan with 16-wave workgroups (k <= 64): grid (grid_x, nq)
+hipError_t launch_scan_i8_wide(int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, bool nt, int unroll,
+                               hipStream_t s)
+{
+    const bool cosine = (metric == VFSX_COSINE || metric == VFSX_SIMD_COSINE);
+    const dim3 grid(grid_x, nq), block(64 * kWideWaves);
+#define VFSX_I8W(M, U, NT)                                                                                         \
+    hipLaunchKernelGGL((scan_i8w_kernel<M, U, NT>), grid, block, 0, s, a.corpus, a.row_norms, a.queries, a.lut,    \
+                       a.lists, a.n_rows, a.d_chunks, a.n_rowblocks, a.q_stride, a.k, a.n_lists)
+#define VFSX_I8W_U(M, NT)                                                                                          \
+    do {                                                                                                           \
+        if (unroll >= 8)                                                                                           \
+            VFSX_I8W(M, 8, NT);                                                                                    \
+        else                                                                                                       \
+            VFSX_I8W(M, 4, NT);                                                                                    \
+    } while (0)
+    if (cosine) {
+        if (nt)
+            VFSX_I8W_U(VFSX_COSINE, true);
+        else
+            VFSX_I8W_U(VFSX_COSINE, false);
+    } else {
+        if (nt)
+            VFSX_I8W_U(VFSX_EUCLIDEAN, true);
+        else
+            VFSX_I8W_U(VFSX_EUCLIDEAN, false);
+    }
+#undef VFSX_I8W_U
+#undef VFSX_I8W
+    return hipGetLastError();
 }
 
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)
