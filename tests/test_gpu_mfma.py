@@ -242,3 +242,25 @@ def test_mfma_scattered_fallbacks_are_compacted(oracle):
     fb = _compare(c, queries, 10, oracle, rows, metric=0)
     assert 0 < fb < 140
     c.close()
+
+
+@pytest.mark.parametrize("nq", [7, 8, 9, 31, 63])
+def test_mfma_small_batches(oracle, nq):
+    """Batches from 8 queries on take the matrix-core path (it overtakes the 8-queries-per-pass scan
+    there, tools/batch_crossover.py); 7 stay on the exact scan.  Same results either way."""
+    import vfs_amd
+    rng = np.random.default_rng(500 + nq)
+    n, d = 45000, 200
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    for metric in (0, 1):
+        c.enable_mfma(True)
+        c.mfma_stats(reset=True)
+        ids_m, dist_m, cnt_m = c.search_batch(queries, 10, metric)
+        assert c.mfma_stats()[0] == (nq if nq >= 8 else 0)
+        for qi in range(nq):
+            oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, 10)
+            assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
+    c.close()

@@ -172,7 +172,7 @@ struct vfsx_corpus {
     DeviceBuf<float> fb_queries;
     DeviceBuf<vfsx_hit> fb_hits;
     bool mirror_bad = false;
-    uint32_t mfma_min_batch = 64;
+    uint32_t mfma_min_batch = 8;
     uint32_t mfma_variant = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
@@ -824,7 +824,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
         c->n_cus = (uint32_t)prop.multiProcessorCount;
         c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
-        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 64);
+        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 8);
         c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
