@@ -268,17 +268,21 @@ __device__ __forceinline__ void acc_step(Acc &acc, float qv, float xv)
     }
 }
 
+// query n of a group, or the group's last real query when the batch ends inside the group (queries read
+// straight from the caller's buffer: no row past the batch is touched)
+__device__ __forceinline__ uint32_t q_slot(int n, uint32_t n_last) { return (uint32_t)n < n_last ? (uint32_t)n : n_last; }
+
 // NQ queries share one pass over the row: element x_j is loaded once and folded into
 // NQ independent accumulators.  `q` points at query 0's chunk, `qs` is the stride
 // (floats) to the next query.  NQ == 1: q is global + wave-uniform -> s_load/SGPR.
 // NQ > 1: q is the workgroup's LDS copy; every lane reads the same address (broadcast).
 template <int METRIC, bool WITH_QQ, int NQ>
 __device__ __forceinline__ void acc_chunk_f32(Acc (&acc)[NQ], const uint4 v, const float *__restrict__ q,
-                                              uint32_t qs)
+                                              uint32_t qs, uint32_t n_last = 0xffffffffu)
 {
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
-        const float4 qv = *(const float4 *)(q + (size_t)n * qs);
+        const float4 qv = *(const float4 *)(q + (size_t)q_slot(n, n_last) * qs);
         acc_step<METRIC, WITH_QQ>(acc[n], qv.x, __uint_as_float(v.x));
         acc_step<METRIC, WITH_QQ>(acc[n], qv.y, __uint_as_float(v.y));
         acc_step<METRIC, WITH_QQ>(acc[n], qv.z, __uint_as_float(v.z));
@@ -291,7 +295,7 @@ __device__ __forceinline__ void acc_chunk_f32(Acc (&acc)[NQ], const uint4 v, con
 // Dequantized once per element, shared by the NQ queries.
 template <int METRIC, bool WITH_QQ, int NQ>
 __device__ __forceinline__ void acc_word_i8(Acc (&acc)[NQ], uint32_t w, const float *__restrict__ q, uint32_t qs,
-                                            const float *lut_lane)
+                                            const float *lut_lane, uint32_t n_last = 0xffffffffu)
 {
     float xv[4];
 #pragma unroll
@@ -299,7 +303,7 @@ __device__ __forceinline__ void acc_word_i8(Acc (&acc)[NQ], uint32_t w, const fl
         xv[b] = lut_lane[((w >> (8 * b)) & 0xffu) * 32u]; // (q as f32) / scale, vector.rs:135-139
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
-        const float4 qv = *(const float4 *)(q + (size_t)n * qs);
+        const float4 qv = *(const float4 *)(q + (size_t)q_slot(n, n_last) * qs);
         acc_step<METRIC, WITH_QQ>(acc[n], qv.x, xv[0]);
         acc_step<METRIC, WITH_QQ>(acc[n], qv.y, xv[1]);
         acc_step<METRIC, WITH_QQ>(acc[n], qv.z, xv[2]);
@@ -309,12 +313,12 @@ __device__ __forceinline__ void acc_word_i8(Acc (&acc)[NQ], uint32_t w, const fl
 
 template <int METRIC, bool WITH_QQ, int NQ>
 __device__ __forceinline__ void acc_chunk_i8(Acc (&acc)[NQ], const uint4 v, const float *__restrict__ q,
-                                             uint32_t qs, const float *lut_lane)
+                                             uint32_t qs, const float *lut_lane, uint32_t n_last = 0xffffffffu)
 {
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.x, q + 0, qs, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.y, q + 4, qs, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.z, q + 8, qs, lut_lane);
-    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.w, q + 12, qs, lut_lane);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.x, q + 0, qs, lut_lane, n_last);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.y, q + 4, qs, lut_lane, n_last);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.z, q + 8, qs, lut_lane, n_last);
+    acc_word_i8<METRIC, WITH_QQ, NQ>(acc, v.w, q + 12, qs, lut_lane, n_last);
 }
 
 template <bool NT>
@@ -333,7 +337,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint4 *p)
 template <int DTYPE, int METRIC, int UNROLL, bool NT, bool WITH_QQ, int NQ>
 __device__ __forceinline__ void scan_rowblock(Acc (&acc)[NQ], const uint4 *__restrict__ p,
                                               const float *__restrict__ q, uint32_t qs, const float *lut_lane,
-                                              uint32_t d_chunks)
+                                              uint32_t d_chunks, uint32_t n_last = 0xffffffffu)
 {
     constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
     uint32_t c = 0;
@@ -345,17 +349,17 @@ __device__ __forceinline__ void scan_rowblock(Acc (&acc)[NQ], const uint4 *__res
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (DTYPE == VFSX_I8)
-                acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs, lut_lane);
+                acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs, lut_lane, n_last);
             else
-                acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs);
+                acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v[u], q + (c + u) * EPC, qs, n_last);
         }
     }
     for (; c < d_chunks; ++c) {
         uint4 v = load_chunk<NT>(p + (size_t)c * 64u);
         if (DTYPE == VFSX_I8)
-            acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs, lut_lane);
+            acc_chunk_i8<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs, lut_lane, n_last);
         else
-            acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs);
+            acc_chunk_f32<METRIC, WITH_QQ, NQ>(acc, v, q + c * EPC, qs, n_last);
     }
 }
 

@@ -52,12 +52,20 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     }
     const float *lut_lane = lut_s + (lane & 31u);
 
-    // query source
+    // query source.  One query: wave-uniform global reads (s_load, SGPR operands).  Several: the same for
+    // int8 stores and for Cosine (MI355X: 11-22 % faster than the LDS copy, whose broadcast reads cost full
+    // LDS bandwidth), the LDS copy for f32 Euclidean (8-15 % faster there).
+    constexpr bool QDIRECT = NQ > 1 && (DTYPE == VFSX_I8 || METRIC == VFSX_COSINE);
     const float *__restrict__ q;
     uint32_t qs;
+    uint32_t n_last = 0xffffffffu;
     if (NQ == 1) {
         q = queries + (size_t)q0 * q_stride;
         qs = 0;
+    } else if (QDIRECT) {
+        q = queries + (size_t)q0 * q_stride;
+        qs = q_stride;
+        n_last = min((uint32_t)NQ, nq - q0) - 1u; // ragged last group: repeat the last query
     } else {
         float *q_s = (float *)(dyn_lds + (size_t)kWavesPerBlock * NQ * list_stride);
         for (uint32_t i = threadIdx.x; i < NQ * q_stride; i += kBlock) {
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
         q = q_s;
         qs = q_stride;
     }
-    if (DTYPE == VFSX_I8 || NQ > 1)
+    if (DTYPE == VFSX_I8 || (NQ > 1 && !QDIRECT))
         __syncthreads();
 
     TopK top[NQ];
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
             acc[n] = Acc{0.0f, 0.0f};
-        scan_rowblock<DTYPE, METRIC, UNROLL, NT, true, NQ>(acc, p, q, qs, lut_lane, d_chunks);
+        scan_rowblock<DTYPE, METRIC, UNROLL, NT, true, NQ>(acc, p, q, qs, lut_lane, d_chunks, n_last);
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
             qn[n] = f_sqrt(acc[n].qq); // rank.rs:296
@@ -155,9 +163,9 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     if (DTYPE == VFSX_I8)
-                        acc_chunk_i8<METRIC, false, NQ>(acc, cur[u], q + (g * UNROLL + u) * EPC, qs, lut_lane);
+                        acc_chunk_i8<METRIC, false, NQ>(acc, cur[u], q + (g * UNROLL + u) * EPC, qs, lut_lane, n_last);
                     else
-                        acc_chunk_f32<METRIC, false, NQ>(acc, cur[u], q + (g * UNROLL + u) * EPC, qs);
+                        acc_chunk_f32<METRIC, false, NQ>(acc, cur[u], q + (g * UNROLL + u) * EPC, qs, n_last);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
                 acc[n] = Acc{0.0f, 0.0f};
-            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false, NQ>(acc, p, q, qs, lut_lane, d_chunks);
+            scan_rowblock<DTYPE, METRIC, UNROLL, NT, false, NQ>(acc, p, q, qs, lut_lane, d_chunks, n_last);
             finish_rowblock(blk, acc);
         }
     }
