@@ -264,3 +264,31 @@ def test_mfma_small_batches(oracle, nq):
             oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, 10)
             assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
     c.close()
+
+
+@pytest.mark.parametrize("mag,qmag,on_mfma", [(1e-6, 1e-6, True), (1e6, 1e6, True), (1e-6, 1.0, True), (1e-6, 1e-12, False),
+                                               (1e-12, 1.0, False), (1e12, 1e12, False), (3e-21, 3e-21, False)])
+def test_mfma_magnitude_guard(mag, qmag, on_mfma):
+    """The batch path's relative error bounds need norms in [2^-30, 2^30] (no subnormal / overflowing
+    intermediate in the reference's sums): rows outside disable the path for the corpus, queries outside take
+    the exact scan.  Either way the result equals the exact scan's bit for bit."""
+    import vfs_amd
+    rng = np.random.default_rng(int(abs(np.log10(mag))) * 31 + int(abs(np.log10(qmag))))
+    n, d = 40000, 64
+    rows = (rng.uniform(-1, 1, (n, d)) * mag).astype(np.float32)
+    q = (rng.uniform(-1, 1, (100, d)) * qmag).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    for metric in (0, 1):
+        c.enable_mfma(True)
+        c.mfma_stats(reset=True)
+        im, dm, cm = c.search_batch(q, 10, metric)
+        nq_m, fb = c.mfma_stats()
+        if on_mfma:  # attempted; with |q| >> |x| the Euclidean check rightly sends every query back
+            assert nq_m == 100 and (fb == 0 or mag != qmag)
+        else:
+            assert nq_m == 0 or fb == nq_m  # path disabled for the corpus, or every query sent back
+        c.enable_mfma(False)
+        ie, de, ce = c.search_batch(q, 10, metric)
+        assert (cm == ce).all() and (im == ie).all() and (bits(dm) == bits(de)).all()
+    c.close()

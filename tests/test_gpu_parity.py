@@ -127,3 +127,39 @@ def test_synthetic_fill_matches_oracle_generator(oracle):
     c.fill_synthetic(seed, n)
     assert (c.get_rows_raw(np.arange(n)) == oracle.synth_i8(seed, 0, n, d)).all()
     c.close()
+
+
+@pytest.mark.parametrize("magnitude", [1e-19, 3e-21, 1e-23, 1e18])
+@pytest.mark.parametrize("metric", [EUCLIDEAN, COSINE])
+def test_subnormal_and_huge_magnitudes(oracle, magnitude, metric):
+    """f32 denormals must stay enabled and sqrt / divide correctly rounded on the device: with
+    rows of magnitude 1e-19 .. 1e-23 the squares, their sums and the norms are subnormal (or flush to zero
+    only where IEEE says so); 1e18 takes the sums close to overflow.  Compared bit for bit."""
+    import vfs_amd
+    rng = np.random.default_rng(int(abs(np.log10(magnitude))) + metric)
+    n, d = 3000, 24
+    rows = (rng.uniform(-1, 1, (n, d)) * magnitude).astype(np.float32)
+    q = (rng.uniform(-1, 1, d) * magnitude).astype(np.float32)
+    if metric == COSINE:  # zero norms give NaN: outside parity (the oracle's norms decide)
+        sq = (rows.astype(np.float32) ** 2).astype(np.float32)
+        acc = np.zeros(n, np.float32)
+        for j in range(d):
+            acc = (acc + sq[:, j]).astype(np.float32)
+        keep = np.sqrt(acc) > 0
+        qacc = np.float32(0)
+        for j in range(d):
+            qacc = np.float32(qacc + np.float32(q[j] * q[j]))
+        if not (np.sqrt(qacc) > 0):
+            pytest.skip("query norm underflows to zero: NaN distances, outside parity")
+        rows = rows[keep]
+        if len(rows) < 100:
+            pytest.skip("row norms underflow to zero: NaN distances, outside parity")
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    for k in (1, 10, 64):
+        _check(c, oracle, rows, q, metric, k)
+    gi, gd, gc = c.search_batch(np.stack([q, q * np.float32(0.5), -q]), 10, metric)
+    for qi, qq in enumerate([q, q * np.float32(0.5), -q]):
+        oi, od, _ = oracle.topk_scan(rows, qq.astype(np.float32), metric, 10)
+        assert (gi[qi] == oi).all() and (_bits(gd[qi]) == _bits(od)).all()
+    c.close()

@@ -49,6 +49,12 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f)
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// The batch path's error bounds (mfma_epsilon, gamma) are RELATIVE f32 bounds: they hold while no product or
+// sum the reference forms is subnormal or overflows.  Norms inside [2^-30, 2^30] guarantee that for everything
+// that matters (a term that still underflows is below 2^-89 of the result's scale).  A row outside the range
+// (or with a zero / non-finite norm) disables the path for the corpus, a query outside it goes to the exact scan.
+__device__ __forceinline__ bool norm_in_mfma_range(float n) { return n >= 0x1p-30f && n <= 0x1p30f; }
+
 // ---- mirror: rb64 corpus -> normalised bf16 in fragment order ----------------------------
 // unit (g, s) = 1 KiB: lane l holds row 32g + (l & 31), k = 16s + 8(l >> 5) .. +7 -- exactly
 // the A/B operand of v_mfma_f32_32x32x16_bf16, so staging is a linear copy and every
@@ -72,7 +78,7 @@ __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < n_rows) {
         const float n2 = row_norms[row];
-        const bool ok = (n2 > 0.0f) && (n2 < __uint_as_float(0x7f800000u));
+        const bool ok = norm_in_mfma_range(n2);
         if (!ok) {
             if (s == 0 && lane < unit_rows)
                 atomicOr(bad_flag, 1);
@@ -126,7 +132,7 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
     for (int o = 32; o > 0; o >>= 1)
         s += __shfl_xor(s, o, 64);
     const float n1 = __builtin_sqrtf(s);
-    const bool ok = (n1 > 0.0f) && (n1 < __uint_as_float(0x7f800000u));
+    const bool ok = norm_in_mfma_range(n1);
     if (lane == 0) {
         q_bad[q] = ok ? 0 : 1;
         q_norm[q] = ok ? n1 : 0.0f; // the scalar the mirror row was divided by (Euclidean epilogue + check)
