@@ -173,6 +173,7 @@ struct vfsx_corpus {
     DeviceBuf<vfsx_hit> fb_hits;
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 8;
+    uint32_t mfma_kp_override = 0; // VFSX_MFMA_KP: first-pass candidates per query (0 = by k)
     uint32_t mfma_variant = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
@@ -581,7 +582,12 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     use_device(c);
     ensure_mirror(c, s);
     const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_variant);
-    const uint32_t kp = k <= 8 ? 64u : (k <= 32 ? 128u : 256u);
+    // first-pass candidates per query; queries with more rows above their safety margin are decided again from
+    // 256 candidates in the second device pass below (C4, k = 10: 64 -> 68.3 ms per batch, 128 -> 70.6 ms, no
+    // query left for the exact scan either way)
+    uint32_t kp = k <= 16 ? 64u : (k <= 32 ? 128u : 256u);
+    if (c->mfma_kp_override == 64u || c->mfma_kp_override == 128u || c->mfma_kp_override == 256u)
+        kp = std::max<uint32_t>(c->mfma_kp_override, k <= 64u ? 64u : 256u); // experiments: VFSX_MFMA_KP
     const float eps = vfsx::mfma_epsilon(g.k_pad);
     const int euclid = is_cosine(metric) ? 0 : 1;
     const float eps_e = eps - 0x1p-13f; // no index bits inside s~ on the Euclidean path (they go into the key)
@@ -825,6 +831,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->n_cus = (uint32_t)prop.multiProcessorCount;
         c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 8);
+        c->mfma_kp_override = (uint32_t)env_u64("VFSX_MFMA_KP", 0);
         c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
