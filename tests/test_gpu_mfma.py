@@ -244,6 +244,29 @@ def test_mfma_scattered_fallbacks_are_compacted(oracle):
     c.close()
 
 
+@pytest.mark.parametrize("nq", [8, 33, 64, 65])
+def test_mfma_skinny_prefilter_int8_and_ragged(oracle, nq):
+    """Batches of <= 64 queries run mfma_prefilter_skinny_kernel (65: the 256-query kernel): int8 store, a
+    ragged last row tile, a dimension that needs K padding, both metrics, against the oracle."""
+    import vfs_amd
+    rng = np.random.default_rng(900 + nq)
+    n, d = 16384 + 256 * 37 + 113, 100
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=True)
+    c.append_f32(rows)
+    ref = oracle.quantize(rows, 127.0)
+    c.enable_mfma(True)
+    for metric in (0, 1):
+        c.mfma_stats(reset=True)
+        ids_m, dist_m, cnt_m = c.search_batch(queries, 10, metric)
+        assert c.mfma_stats()[0] == nq
+        for qi in range(0, nq, 7):
+            oi, od, _ = oracle.topk_scan(ref, queries[qi], metric, 10, scale=127.0)
+            assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
+    c.close()
+
+
 @pytest.mark.parametrize("nq", [7, 8, 9, 31, 63])
 def test_mfma_small_batches(oracle, nq):
     """Batches from 8 queries on take the matrix-core path (it overtakes the 8-queries-per-pass scan

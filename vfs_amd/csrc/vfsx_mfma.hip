@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "vfsx_device.h"
@@ -168,6 +169,9 @@ __device__ __forceinline__ void glds16_untracked(const uint4 *g, uint4 *lds_wave
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)(uintptr_t)a, 16, 0, 0);
 }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 frag_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
 {
@@ -604,6 +608,210 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
             cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
             cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+        }
+    }
+}
+
+// ---- prefilter for small batches (<= 64 queries): 256 rows x 64 queries per workgroup ---------------------
+// One partly filled 256-query tile makes mfma_prefilter256_kernel latency-bound: a single workgroup per CU
+// with one 64 KiB stage in flight moves the mirror at ~3.7 TB/s, and 3/4 of its MFMAs multiply zero columns.
+// Here a stage is 32 KiB of rows + 8 KiB of queries (BK = 64) in a ring of NSTAGE slots with NSTAGE-1 stages
+// in flight, each of the 8 waves multiplies its own 32 rows by the 64 queries (2 MFMAs per k-slice), and the
+// kernel runs at the mirror's HBM rate.  Output: the candidate lists of mfma_prefilter256_kernel, bit for bit
+// the same format (wave w covers what (wave_m, mi) = (w >> 2, w & 3) covers there; the four waves of one
+// wave_m merge their top-3 through LDS at the end), so select / re-score are shared.
+template <int NSTAGE, int MODE>
+__global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 *__restrict__ A,
+                                                                    const uint4 *__restrict__ B,
+                                                                    float *__restrict__ cand, uint32_t n_rows,
+                                                                    uint32_t n_rowtiles, uint32_t KS, uint32_t nq,
+                                                                    uint32_t n_lists, uint32_t strip_tiles,
+                                                                    const float2 *__restrict__ rn2,
+                                                                    const float *__restrict__ q_norm, float eps_e)
+{
+    constexpr uint32_t KU = 4u, TROWS = 256u;
+    constexpr uint32_t A_UNITS = 8u * KU, UNITS = 10u * KU; // 32 row units + 8 query units of 1 KiB per stage
+    static_assert(NSTAGE >= 3 && NSTAGE <= 4, "ring depth"); // 3 and 4 measure the same (0.48 ms at 1M x 768)
+    __shared__ __align__(16) uint4 ring[NSTAGE * UNITS * 64];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
+    const uint32_t wave_m = wave >> 2, mi = wave & 3u;
+    const uint32_t strip = blockIdx.x;
+    const uint32_t tile0 = strip * strip_tiles;
+    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
+    const uint32_t KT = KS / KU;
+    const uint32_t n_it = ntiles * KT;
+
+    // staging: every wave moves 4 row pieces (its own 32-row group, the 4 k-slices) and 1 query piece per stage
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t tile_bytes = 8u * KS * 1024u; // one 256-row tile of the mirror
+    const uint32_t a_soff = wave * KS * 1024u, a_lds = wave * KU * 1024u;
+    const uint32_t b_soff = ((wave >> 2) * KS + (wave & 3u)) * 1024u, b_lds = (A_UNITS + wave) * 1024u;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)ring;
+    uintptr_t nx_base = (uintptr_t)A + (uintptr_t)tile0 * tile_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, 0xffffffff, 0x00020000);
+    uint32_t nx_idx = 0, nx_koff = 0, nx_slot = 0;
+    auto stage = [&]() { // issue the next stage into the next ring slot (past the end: re-issue the last one)
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, 0xffffffff, 0x00020000);
+        const uint32_t slot_base = ring_base + nx_slot * (UNITS * 1024u);
+#pragma unroll
+        for (uint32_t u = 0; u < KU; ++u) {
+            uint32_t a = slot_base + a_lds + u * 1024u;
+            asm volatile("" : "+s"(a)); // LDS destination laundered: see glds16_untracked
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
+                                                     (int)lane16, (int)(a_soff + u * 1024u + nx_koff), 0, 0);
+        }
+        uint32_t b = slot_base + b_lds;
+        asm volatile("" : "+s"(b));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(uintptr_t)b, 16,
+                                                 (int)lane16, (int)(b_soff + nx_koff), 0, 0);
+        nx_slot = nx_slot + 1u == (uint32_t)NSTAGE ? 0u : nx_slot + 1u;
+        if (nx_idx + 1u < n_it) {
+            ++nx_idx;
+            nx_koff += KU * 1024u;
+            if (nx_koff == KS * 1024u) {
+                nx_koff = 0;
+                nx_base += tile_bytes;
+            }
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[ni][r] = 0.0f;
+    const float ninf = __uint_as_float(0xff800000u);
+    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
+    uint32_t keep_mask = ~kIdxMask;
+    asm volatile("" : "+v"(keep_mask));
+    float cq[2] = {0.0f, 0.0f}; // MODE 1: 2a per query column
+    if (MODE == 1) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
+            cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
+        }
+    }
+    auto insert3 = [&](int ni, float sp) __attribute__((always_inline)) {
+        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
+    };
+    auto fold_tile = [&](uint32_t ts, uint32_t tile_row0) __attribute__((always_inline)) {
+        const bool ragged = tile_row0 + TROWS > n_rows;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const uint32_t row4 = tile_row0 + wave_m * 128u + mi * 32u + 8u * (uint32_t)rq + 4u * (lane >> 5);
+            float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) {
+                const float4 p0 = *(const float4 *)(rn2 + row4);
+                const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
+                bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
+                bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
+            }
+#pragma unroll
+            for (int rl = 0; rl < 4; ++rl) {
+                const int r = rq * 4 + rl;
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | (mi << 4) | (uint32_t)r));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = acc[ni][r];
+                    if (MODE == 1)
+                        v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
+                    float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
+                    if (ragged && row4 + (uint32_t)rl >= n_rows)
+                        sp = ninf;
+                    insert3(ni, sp);
+                    acc[ni][r] = 0.0f;
+                }
+            }
+        }
+    };
+
+    for (int j = 0; j < NSTAGE - 1; ++j)
+        stage();
+    uint32_t cur_kt = 0, cur_ts = 0, rd_slot = 0;
+    for (uint32_t it = 0; it < n_it; ++it) {
+        // 5 pieces per wave and stage; NSTAGE-2 younger stages stay in flight behind the one consumed now
+        if (NSTAGE == 4)
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(); // into the slot consumed in the previous step (every wave is past it: barrier above)
+        // The 12 fragment reads of the K-step as asm: hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of
+        // any ds_read it cannot prove independent of a pending LDS-DMA (here: the stage issued two lines up),
+        // which would serialise every stage with its K-step.  The ring protocol above is what orders them.
+        const uint32_t rd_a = ring_base + rd_slot * (UNITS * 1024u) + wave * (KU * 1024u) + lane16;
+        const uint32_t rd_b = ring_base + rd_slot * (UNITS * 1024u) + A_UNITS * 1024u + lane16;
+        rd_slot = rd_slot + 1u == (uint32_t)NSTAGE ? 0u : rd_slot + 1u;
+        u32x4 fa[4], fb[8];
+#define VFSX_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+        VFSX_DSR(fa[0], rd_a, 0);
+        VFSX_DSR(fb[0], rd_b, 0);
+        VFSX_DSR(fb[4], rd_b, 4096);
+        VFSX_DSR(fa[1], rd_a, 1024);
+        VFSX_DSR(fb[1], rd_b, 1024);
+        VFSX_DSR(fb[5], rd_b, 5120);
+        VFSX_DSR(fa[2], rd_a, 2048);
+        VFSX_DSR(fb[2], rd_b, 2048);
+        VFSX_DSR(fb[6], rd_b, 6144);
+        VFSX_DSR(fa[3], rd_a, 3072);
+        VFSX_DSR(fb[3], rd_b, 3072);
+        VFSX_DSR(fb[7], rd_b, 7168);
+#undef VFSX_DSR
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
+                       "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7])
+                     :
+                     : "memory");
+#pragma unroll
+        for (uint32_t ks = 0; ks < KU; ++ks) {
+#pragma unroll
+            for (uint32_t ni = 0; ni < 2; ++ni)
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bf16x8(fa[ks]), frag_bf16x8(fb[ni * 4u + ks]),
+                                                                  acc[ni], 0, 0, 0);
+        }
+        if (++cur_kt == KT) {
+            const uint32_t ts = cur_ts;
+            cur_kt = 0;
+            ++cur_ts;
+            fold_tile(ts, (tile0 + ts) * TROWS);
+        }
+    }
+    // the redundant tail stages must land before the ring is reused / released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // merge the four waves of one wave_m: [wave][ni][3][64] floats in the (now idle) ring
+    float *xch = (float *)ring;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        xch[((wave * 2u + ni) * 3u + 0u) * 64u + lane] = m1[ni];
+        xch[((wave * 2u + ni) * 3u + 1u) * 64u + lane] = m2[ni];
+        xch[((wave * 2u + ni) * 3u + 2u) * 64u + lane] = m3[ni];
+    }
+    __syncthreads();
+    if (mi == 0u) {
+        for (uint32_t w = wave + 1u; w < wave + 4u; ++w)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (uint32_t j = 0; j < 3u; ++j)
+                    insert3(ni, xch[((w * 2u + ni) * 3u + j) * 64u + lane]);
+        const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
+            if (q < nq) {
+                cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
+                cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
+                cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+            }
         }
     }
 }
@@ -1127,7 +1335,16 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
         else
             VFSX_PF256(2, 4, 0);
     } else if (g.variant == 1) {
-        if (euclid)
+        // <= 64 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
+        static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
+        if (skinny_on && nq <= 64u) {
+            if (euclid)
+                hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, 1>), dim3(g.n_strips), dim3(512), 0, s, mirror, qm,
+                                   cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
+            else
+                hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, 0>), dim3(g.n_strips), dim3(512), 0, s, mirror, qm,
+                                   cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
+        } else if (euclid)
             VFSX_PF256(4, 2, 1);
         else
             VFSX_PF256(4, 2, 0);
