@@ -266,7 +266,7 @@ int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint
  * Many-query batches on the matrix cores (no reference counterpart: the reference has no
  * multi-query API, rank.rs:90; a batch is defined as the single-query result per query).
  * Enabling builds a bf16 mirror of the corpus (+2 bytes per element of HBM).  Afterwards
- * vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 8
+ * vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 (f32 stores) / 8 (int8 stores)
  * queries with k <= 64 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the exact scan)
  * through Q.X^T on MFMA + an exact sequential re-score of the surviving candidates + a
  * rigorous bound check, and re-run the exact scan for any query the check cannot clear:

@@ -267,10 +267,10 @@ def test_mfma_skinny_prefilter_int8_and_ragged(oracle, nq):
     c.close()
 
 
-@pytest.mark.parametrize("nq", [7, 8, 9, 31, 63])
+@pytest.mark.parametrize("nq", [3, 4, 7, 8, 9, 31, 63])
 def test_mfma_small_batches(oracle, nq):
-    """Batches from 8 queries on take the matrix-core path (it overtakes the 8-queries-per-pass scan
-    there, tools/batch_crossover.py); 7 stay on the exact scan.  Same results either way."""
+    """Batches from 4 queries on (f32 stores; 8 for int8) take the matrix-core path (it overtakes the
+    multi-query scan there, tools/batch_crossover.py); 3 stay on the exact scan.  Same results either way."""
     import vfs_amd
     rng = np.random.default_rng(500 + nq)
     n, d = 45000, 200
@@ -282,7 +282,7 @@ def test_mfma_small_batches(oracle, nq):
         c.enable_mfma(True)
         c.mfma_stats(reset=True)
         ids_m, dist_m, cnt_m = c.search_batch(queries, 10, metric)
-        assert c.mfma_stats()[0] == (nq if nq >= 8 else 0)
+        assert c.mfma_stats()[0] == (nq if nq >= 4 else 0)
         for qi in range(nq):
             oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, 10)
             assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()

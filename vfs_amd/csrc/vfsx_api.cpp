@@ -830,7 +830,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
         c->n_cus = (uint32_t)prop.multiProcessorCount;
         c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
-        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 8);
+        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", dtype == VFSX_I8 ? 8 : 4); // measured crossover
         c->mfma_kp_override = (uint32_t)env_u64("VFSX_MFMA_KP", 0);
         c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
