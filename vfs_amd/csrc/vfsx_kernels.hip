@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void scan_i8w_kernel(
 // One workgroup per query.  Lists arrive column-major ([j][list], each list ascending).
 // A lane owns one list and walks it only while its entries still beat the wave's
 // current k-th best (tau only shrinks, entries only grow): with random data that is
-// 1-2 columns, i.e. 1-2 HBM/L2 round trips, instead of reading and offering everything.
+// 2-3 columns, i.e. one HBM/L2 round trip of four columns, instead of reading and offering everything.
 template <typename TopK, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__restrict__ lists,
                                                             const uint64_t *__restrict__ ids,
@@ -343,15 +343,18 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
     for (uint32_t lbase = wave * 64u; lbase < n_lists; lbase += BLOCK) { // wave-uniform
         const uint32_t list = lbase + lane;
         bool alive = list < n_lists;
-        for (uint32_t j = 0; j < k; j += 2) {
-            // two columns per round trip
-            uint64_t c0 = alive ? src[(size_t)j * n_lists + list] : kSentinel;
-            uint64_t c1 = (alive && j + 1 < k) ? src[(size_t)(j + 1) * n_lists + list] : kSentinel;
-            alive = alive && (c1 < top.tau);
-            if (__ballot(c0 < top.tau) == 0)
+        for (uint32_t j = 0; j < k; j += 4) {
+            // four columns per round trip (the lists were just written by other CUs: every trip is ~2 us)
+            uint64_t c[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                c[u] = (alive && j + u < k) ? src[(size_t)(j + u) * n_lists + list] : kSentinel;
+            if (__ballot(c[0] < top.tau) == 0)
                 break;
-            top.offer(c0);
-            top.offer(c1);
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                top.offer(c[u]);
+            alive = alive && (c[3] < top.tau);
             if (__ballot(alive) == 0)
                 break;
         }
