@@ -92,6 +92,30 @@ def test_c3_10m_x128_int8_euclidean(oracle):
     c.close()
 
 
+def test_c3_size_int8_cosine_and_k64(oracle):
+    """The 16-wave int8 kernel (scan_i8w_kernel) at C3 size for Cosine and for k = 64, against the oracle's
+    scan of the whole corpus (slabs merged by (distance, scan position))."""
+    import vfs_amd
+    n, d = 10_000_000, 128
+    c = vfs_amd.Corpus(d, quantize=True, capacity_rows=n)
+    c.fill_synthetic(SEED_C, n)
+    q = oracle.synth_f32(SEED_Q, 3, 1, d)[0]
+    slab = 1_000_000
+    slabs = [oracle.synth_i8(SEED_C, r0, slab, d) for r0 in range(0, n, slab)]
+    for metric, k in ((1, 10), (0, 64), (1, 64)):
+        ids, dist, cnt = c.search_batch(q, k, metric)
+        parts = []
+        for si, rows in enumerate(slabs):
+            oi, od, op = oracle.topk_scan(rows, q, metric, k)
+            parts.append((od, op + si * slab))
+        od = np.concatenate([p[0] for p in parts])
+        op = np.concatenate([p[1] for p in parts])
+        order = np.lexsort((op, od))[:k]
+        assert (ids[0] == op[order] + 1).all(), (metric, k)
+        assert (bits(dist[0]) == bits(od[order])).all(), (metric, k)
+    c.close()
+
+
 def test_c4_10m_x1024_mfma_batch_equals_exact_scan(oracle):
     """BASELINE config 4 at full size: a 4096-query Cosine batch through the MFMA path must
     equal the exact scan (itself checked against the oracle above) on sampled queries, and a
