@@ -244,10 +244,11 @@ def test_mfma_scattered_fallbacks_are_compacted(oracle):
     c.close()
 
 
-@pytest.mark.parametrize("nq", [8, 33, 64, 65])
+@pytest.mark.parametrize("nq", [8, 33, 64, 65, 100, 128, 129])
 def test_mfma_skinny_prefilter_int8_and_ragged(oracle, nq):
-    """Batches of <= 64 queries run mfma_prefilter_skinny_kernel (65: the 256-query kernel): int8 store, a
-    ragged last row tile, a dimension that needs K padding, both metrics, against the oracle."""
+    """Batches of <= 128 queries run mfma_prefilter_skinny_kernel (one 64-query column up to 64, two up to 128;
+    129: the 256-query kernel): int8 store, a ragged last row tile, a dimension that needs K padding, both
+    metrics, against the oracle."""
     import vfs_amd
     rng = np.random.default_rng(900 + nq)
     n, d = 16384 + 256 * 37 + 113, 100

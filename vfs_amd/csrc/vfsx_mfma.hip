@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 // kernel runs at the mirror's HBM rate.  Output: the candidate lists of mfma_prefilter256_kernel, bit for bit
 // the same format (wave w covers what (wave_m, mi) = (w >> 2, w & 3) covers there; the four waves of one
 // wave_m merge their top-3 through LDS at the end), so select / re-score are shared.
-template <int NSTAGE, int MODE>
+template <int NSTAGE, int MODE, int NCOL>
 __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 *__restrict__ A,
                                                                     const uint4 *__restrict__ B,
                                                                     float *__restrict__ cand, uint32_t n_rows,
@@ -630,7 +630,10 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                                                                     const float *__restrict__ q_norm, float eps_e)
 {
     constexpr uint32_t KU = 4u, TROWS = 256u;
-    constexpr uint32_t A_UNITS = 8u * KU, UNITS = 10u * KU; // 32 row units + 8 query units of 1 KiB per stage
+    // NCOL = 64-query columns per workgroup (1: <= 64 queries, 2: <= 128): 32 row units + 8 NCOL query units of
+    // 1 KiB per stage; every wave multiplies its 32 rows by all 64 NCOL queries
+    constexpr uint32_t A_UNITS = 8u * KU, UNITS = (8u + 2u * NCOL) * KU;
+    constexpr int NI = 2 * NCOL;
     static_assert(NSTAGE >= 3 && NSTAGE <= 4, "ring depth"); // 3 and 4 measure the same (0.48 ms at 1M x 768)
     __shared__ __align__(16) uint4 ring[NSTAGE * UNITS * 64];
 
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
     const uint32_t lane16 = lane * 16u;
     const uint32_t tile_bytes = 8u * KS * 1024u; // one 256-row tile of the mirror
     const uint32_t a_soff = wave * KS * 1024u, a_lds = wave * KU * 1024u;
+    // query pieces: wave w moves (32-query group w >> 2 [+ 2 for the second column], k-slice w & 3)
     const uint32_t b_soff = ((wave >> 2) * KS + (wave & 3u)) * 1024u, b_lds = (A_UNITS + wave) * 1024u;
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)ring;
     uintptr_t nx_base = (uintptr_t)A + (uintptr_t)tile0 * tile_bytes;
@@ -662,10 +666,13 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
                                                      (int)lane16, (int)(a_soff + u * 1024u + nx_koff), 0, 0);
         }
-        uint32_t b = slot_base + b_lds;
-        asm volatile("" : "+s"(b));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(uintptr_t)b, 16,
-                                                 (int)lane16, (int)(b_soff + nx_koff), 0, 0);
+#pragma unroll
+        for (uint32_t col = 0; col < (uint32_t)NCOL; ++col) {
+            uint32_t b = slot_base + b_lds + col * (8u * 1024u);
+            asm volatile("" : "+s"(b));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(uintptr_t)b, 16,
+                                                     (int)lane16, (int)(b_soff + col * (2u * KS * 1024u) + nx_koff), 0, 0);
+        }
         nx_slot = nx_slot + 1u == (uint32_t)NSTAGE ? 0u : nx_slot + 1u;
         if (nx_idx + 1u < n_it) {
             ++nx_idx;
@@ -677,20 +684,26 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[NI];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             acc[ni][r] = 0.0f;
     const float ninf = __uint_as_float(0xff800000u);
-    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
+    float m1[NI], m2[NI], m3[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        m1[ni] = m2[ni] = m3[ni] = ninf;
     uint32_t keep_mask = ~kIdxMask;
     asm volatile("" : "+v"(keep_mask));
-    float cq[2] = {0.0f, 0.0f}; // MODE 1: 2a per query column
+    float cq[NI]; // MODE 1: 2a per query column
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        cq[ni] = 0.0f;
     if (MODE == 1) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
             cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
         }
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                 const int r = rq * 4 + rl;
                 const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | (mi << 4) | (uint32_t)r));
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     float v = acc[ni][r];
                     if (MODE == 1)
                         v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
@@ -735,11 +748,15 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
         stage();
     uint32_t cur_kt = 0, cur_ts = 0, rd_slot = 0;
     for (uint32_t it = 0; it < n_it; ++it) {
-        // 5 pieces per wave and stage; NSTAGE-2 younger stages stay in flight behind the one consumed now
-        if (NSTAGE == 4)
+        // 4 + NCOL pieces per wave and stage; NSTAGE-2 younger stages stay in flight behind the one consumed now
+        if ((4 + NCOL) * (NSTAGE - 2) == 5)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if ((4 + NCOL) * (NSTAGE - 2) == 6)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if ((4 + NCOL) * (NSTAGE - 2) == 10)
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stage(); // into the slot consumed in the previous step (every wave is past it: barrier above)
@@ -749,30 +766,50 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
         const uint32_t rd_a = ring_base + rd_slot * (UNITS * 1024u) + wave * (KU * 1024u) + lane16;
         const uint32_t rd_b = ring_base + rd_slot * (UNITS * 1024u) + A_UNITS * 1024u + lane16;
         rd_slot = rd_slot + 1u == (uint32_t)NSTAGE ? 0u : rd_slot + 1u;
-        u32x4 fa[4], fb[8];
+        u32x4 fa[4], fb[4 * NI];
 #define VFSX_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
         VFSX_DSR(fa[0], rd_a, 0);
-        VFSX_DSR(fb[0], rd_b, 0);
-        VFSX_DSR(fb[4], rd_b, 4096);
         VFSX_DSR(fa[1], rd_a, 1024);
-        VFSX_DSR(fb[1], rd_b, 1024);
-        VFSX_DSR(fb[5], rd_b, 5120);
         VFSX_DSR(fa[2], rd_a, 2048);
-        VFSX_DSR(fb[2], rd_b, 2048);
-        VFSX_DSR(fb[6], rd_b, 6144);
         VFSX_DSR(fa[3], rd_a, 3072);
+        VFSX_DSR(fb[0], rd_b, 0);
+        VFSX_DSR(fb[1], rd_b, 1024);
+        VFSX_DSR(fb[2], rd_b, 2048);
         VFSX_DSR(fb[3], rd_b, 3072);
+        VFSX_DSR(fb[4], rd_b, 4096);
+        VFSX_DSR(fb[5], rd_b, 5120);
+        VFSX_DSR(fb[6], rd_b, 6144);
         VFSX_DSR(fb[7], rd_b, 7168);
+        if (NCOL == 2) {
+            VFSX_DSR(fb[4 * NI - 8], rd_b, 8192);
+            VFSX_DSR(fb[4 * NI - 7], rd_b, 9216);
+            VFSX_DSR(fb[4 * NI - 6], rd_b, 10240);
+            VFSX_DSR(fb[4 * NI - 5], rd_b, 11264);
+            VFSX_DSR(fb[4 * NI - 4], rd_b, 12288);
+            VFSX_DSR(fb[4 * NI - 3], rd_b, 13312);
+            VFSX_DSR(fb[4 * NI - 2], rd_b, 14336);
+            VFSX_DSR(fb[4 * NI - 1], rd_b, 15360);
+        }
 #undef VFSX_DSR
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
-                       "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7])
-                     :
-                     : "memory");
+        // fb[ni * 4 + ks] = query group ni, k-slice ks (LDS unit A_UNITS + ni * KU + ks)
+        if (NCOL == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
+                           "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7]), "+v"(fb[4 * NI - 8]),
+                           "+v"(fb[4 * NI - 7]), "+v"(fb[4 * NI - 6]), "+v"(fb[4 * NI - 5]), "+v"(fb[4 * NI - 4]),
+                           "+v"(fb[4 * NI - 3]), "+v"(fb[4 * NI - 2]), "+v"(fb[4 * NI - 1])
+                         :
+                         : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
+                           "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7])
+                         :
+                         : "memory");
 #pragma unroll
         for (uint32_t ks = 0; ks < KU; ++ks) {
 #pragma unroll
-            for (uint32_t ni = 0; ni < 2; ++ni)
+            for (uint32_t ni = 0; ni < (uint32_t)NI; ++ni)
                 acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bf16x8(fa[ks]), frag_bf16x8(fb[ni * 4u + ks]),
                                                                   acc[ni], 0, 0, 0);
         }
@@ -790,22 +827,22 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
     // merge the four waves of one wave_m: [wave][ni][3][64] floats in the (now idle) ring
     float *xch = (float *)ring;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        xch[((wave * 2u + ni) * 3u + 0u) * 64u + lane] = m1[ni];
-        xch[((wave * 2u + ni) * 3u + 1u) * 64u + lane] = m2[ni];
-        xch[((wave * 2u + ni) * 3u + 2u) * 64u + lane] = m3[ni];
+    for (int ni = 0; ni < NI; ++ni) {
+        xch[((wave * NI + ni) * 3u + 0u) * 64u + lane] = m1[ni];
+        xch[((wave * NI + ni) * 3u + 1u) * 64u + lane] = m2[ni];
+        xch[((wave * NI + ni) * 3u + 2u) * 64u + lane] = m3[ni];
     }
     __syncthreads();
     if (mi == 0u) {
         for (uint32_t w = wave + 1u; w < wave + 4u; ++w)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (uint32_t j = 0; j < 3u; ++j)
-                    insert3(ni, xch[((w * 2u + ni) * 3u + j) * 64u + lane]);
+                    insert3(ni, xch[((w * NI + ni) * 3u + j) * 64u + lane]);
         const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
             if (q < nq) {
                 cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
@@ -1337,13 +1374,22 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
     } else if (g.variant == 1) {
         // <= 64 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
         static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
-        if (skinny_on && nq <= 64u) {
-            if (euclid)
-                hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, 1>), dim3(g.n_strips), dim3(512), 0, s, mirror, qm,
-                                   cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
-            else
-                hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, 0>), dim3(g.n_strips), dim3(512), 0, s, mirror, qm,
-                                   cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
+        if (skinny_on && nq <= 128u) {
+#define VFSX_SKINNY(MODE, NCOL)                                                                                    \
+    hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL>), dim3(g.n_strips), dim3(512), 0, s, mirror,   \
+                       qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e)
+            if (nq <= 64u) {
+                if (euclid)
+                    VFSX_SKINNY(1, 1);
+                else
+                    VFSX_SKINNY(0, 1);
+            } else {
+                if (euclid)
+                    VFSX_SKINNY(1, 2);
+                else
+                    VFSX_SKINNY(0, 2);
+            }
+#undef VFSX_SKINNY
         } else if (euclid)
             VFSX_PF256(4, 2, 1);
         else
