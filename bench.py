@@ -250,9 +250,7 @@ def main() -> int:
     if mfma:
         out["roofline"] = {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                           "kernel": {"0": "mfma_prefilter256_kernel", "1": "mfma_prefilter256_kernel",
-                                      "4": "mfma_prefilter256x_kernel"}.get(os.environ.get("VFSX_MFMA_VARIANT", "1"),
-                                                                             "mfma_prefilter_kernel"), "avg_kernel_ms": round(avg_ms, 4),
+                           "kernel": "mfma_prefilter256_kernel", "avg_kernel_ms": round(avg_ms, 4),
                            "algorithmic_flops_per_launch": flops, "launches_timed": int(scan_launches)}
         out["mfma_queries"] = int(mq)
         out["mfma_fallback_queries"] = int(mf)

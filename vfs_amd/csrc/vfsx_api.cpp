@@ -164,17 +164,16 @@ struct vfsx_corpus {
     uint4 *d_mirror = nullptr;
     uint64_t mirror_rows = 0; // rows the mirror currently covers (0 = stale / absent)
     size_t mirror_bytes = 0;
-    int *d_mirror_bad = nullptr; // device flag: a row with zero / non-finite norm exists
+    uint32_t *d_mirror_stats = nullptr; // device: [0] a row norm outside the path's range exists, [1] R_x (vfsx_mfma.hip)
     float *d_rn2 = nullptr;      // [mirror rows padded] float2 (b, b^2 (1 - gamma)) for Euclidean batches
     size_t rn2_rows = 0;
-    DeviceBuf<float> q_norm;
+    DeviceBuf<float> q_norm, q_eps;
     DeviceBuf<uint32_t> fb_idx;  // exact fallback of flagged queries: their indices, compacted copies, hits
     DeviceBuf<float> fb_queries;
     DeviceBuf<vfsx_hit> fb_hits;
     bool mirror_bad = false;
     uint32_t mfma_min_batch = 8;
     uint32_t mfma_kp_override = 0; // VFSX_MFMA_KP: first-pass candidates per query (0 = by k)
-    uint32_t mfma_variant = 1; // prefilter kernel variant (vfsx::mfma_geometry): 1 = 256 x 256 tile, BK 64, 2 slots
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
     DeviceBuf<float> cand;
@@ -541,33 +540,29 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
 {
     if (c->mirror_rows == c->n_rows && c->d_mirror)
         return;
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_variant);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
     if (g.mirror_bytes > c->mirror_bytes) {
         free_mirror(c);
         HIP_CHECK(hipMalloc((void **)&c->d_mirror, g.mirror_bytes));
         c->mirror_bytes = g.mirror_bytes;
     }
-    if (!c->d_mirror_bad)
-        HIP_CHECK(hipMalloc((void **)&c->d_mirror_bad, sizeof(int)));
-    HIP_CHECK(hipMemsetAsync(c->d_mirror_bad, 0, sizeof(int), s));
+    if (!c->d_mirror_stats)
+        HIP_CHECK(hipMalloc((void **)&c->d_mirror_stats, 2 * sizeof(uint32_t)));
+    HIP_CHECK(hipMemsetAsync(c->d_mirror_stats, 0, 2 * sizeof(uint32_t), s));
     HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror, (uint32_t)c->n_rows,
-                                       c->dim, c->d_chunks, g.KS,
-                                       (uint32_t)(g.mirror_bytes / ((size_t)g.k_pad * 2u * g.unit_rows)), g.unit_rows,
-                                       c->d_mirror_bad, s));
-    if (g.tile_queries == 256u) { // Euclidean batches (256 x 256 kernels only)
-        const size_t n_pad = (size_t)g.n_rowtiles * g.wave_rows * g.wm;
-        if (n_pad > c->rn2_rows) {
-            if (c->d_rn2)
-                (void)hipFree(c->d_rn2);
-            c->d_rn2 = nullptr;
-            HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
-            c->rn2_rows = n_pad;
-        }
-        HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad,
-                                                  mfma_gamma(g.k_pad), c->d_rn2, s));
+                                       c->dim, c->d_chunks, g, c->d_mirror_stats, s));
+    const size_t n_pad = (size_t)g.n_rowtiles * 256u; // Euclidean batches: (b, b^2 (1 - gamma)) per row
+    if (n_pad > c->rn2_rows) {
+        if (c->d_rn2)
+            (void)hipFree(c->d_rn2);
+        c->d_rn2 = nullptr;
+        HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
+        c->rn2_rows = n_pad;
     }
-    int bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad, mfma_gamma(g.k_pad),
+                                              c->d_rn2, s));
+    uint32_t bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_stats, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     c->mirror_bad = bad != 0;
     c->mirror_rows = c->n_rows;
@@ -581,16 +576,14 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 {
     use_device(c);
     ensure_mirror(c, s);
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, c->mfma_variant);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
     // first-pass candidates per query; queries with more rows above their safety margin are decided again from
     // 256 candidates in the second device pass below (C4, k = 10: 64 -> 68.3 ms per batch, 128 -> 70.6 ms, no
     // query left for the exact scan either way)
     uint32_t kp = k <= 16 ? 64u : (k <= 32 ? 128u : 256u);
     if (c->mfma_kp_override == 64u || c->mfma_kp_override == 128u || c->mfma_kp_override == 256u)
         kp = std::max<uint32_t>(c->mfma_kp_override, k <= 64u ? 64u : 256u); // experiments: VFSX_MFMA_KP
-    const float eps = vfsx::mfma_epsilon(g.k_pad);
     const int euclid = is_cosine(metric) ? 0 : 1;
-    const float eps_e = eps - 0x1p-13f; // no index bits inside s~ on the Euclidean path (they go into the key)
 
     const uint32_t q_stride_pad = c->d_chunks * c->epc;
     const bool need_pad = (q_stride_pad != c->dim);
@@ -611,6 +604,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
     c->q_bad.reserve(nq);
     c->q_norm.reserve(nq);
+    c->q_eps.reserve(nq);
     c->q_flags.reserve(nq);
     c->h_flags.assign(nq, 0);
 
@@ -619,11 +613,11 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         const uint32_t qn_pad = (qn + 255u) / 256u * 256u;
         HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * 2u, s));
         HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
-                                               g.unit_rows, c->q_bad.p + q0, c->q_norm.p + q0, s));
+                                               c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0, c->d_mirror_stats, s));
         size_t slot = 0;
         prof_begin(c, s, slot);
         HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
-                                              c->d_rn2, c->q_norm.p + q0, eps_e, s));
+                                              c->d_rn2, c->q_norm.p + q0, c->q_eps.p + q0, s));
         prof_end(c, s, slot);
         HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, nullptr, s));
         vfsx::MfmaRescoreArgs a{};
@@ -641,12 +635,10 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.q_stride = q_stride;
         a.k = k;
         a.kp = kp;
-        a.eps = eps;
+        a.q_eps = c->q_eps.p + q0;
         a.row_base = c->row_base;
         a.id_base = c->id_base;
         a.strip_tiles = g.strip_tiles;
-        a.wm = g.wm;
-        a.wave_rows = g.cand_layout;
         a.euclid = euclid;
         a.q_norm = c->q_norm.p + q0;
         a.gamma = mfma_gamma(g.k_pad);
@@ -716,9 +708,9 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         return;
     if (!d_queries || !d_hits)
         fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
-    // Cosine on every prefilter kernel; Euclidean (the reference's metric or its Simd twin) on the 256 x 256 ones
-    const bool metric_ok = is_cosine(metric) || ((metric == VFSX_EUCLIDEAN || metric == VFSX_SIMD_EUCLIDEAN) && (c->mfma_variant <= 1u || c->mfma_variant == 4u));
-    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 &&
+    // the reference's four metrics; the integer-domain extension has its own kernel
+    const bool metric_ok = metric != VFSX_EUCLIDEAN_I8DOMAIN;
+    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 && c->dim <= vfsx::kMfmaMaxDim &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok && c->mfma_backoff > 0) {
         --c->mfma_backoff; // see vfsx_corpus::mfma_backoff
@@ -832,7 +824,6 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", dtype == VFSX_I8 ? 8 : 4); // measured crossover
         c->mfma_kp_override = (uint32_t)env_u64("VFSX_MFMA_KP", 0);
-        c->mfma_variant = (uint32_t)std::min<uint64_t>(4, env_u64("VFSX_MFMA_VARIANT", 1));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
         if (dtype == VFSX_I8)
@@ -870,11 +861,12 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
             (void)hipEventDestroy(c->stage_done[i]);
     }
     free_mirror(c);
-    if (c->d_mirror_bad)
-        (void)hipFree(c->d_mirror_bad);
+    if (c->d_mirror_stats)
+        (void)hipFree(c->d_mirror_stats);
     c->q_mirror.release();
     c->q_bad.release();
     c->q_norm.release();
+    c->q_eps.release();
     c->fb_idx.release();
     c->fb_queries.release();
     c->fb_hits.release();

@@ -89,23 +89,17 @@ hipError_t launch_scan_i8dom(const ScanArgs &a, uint32_t nq, uint32_t grid_x, bo
 
 // ---- many-query batches on the matrix cores (vfsx_mfma.hip) ---------------------------------
 struct MfmaGeometry {
-    uint32_t k_pad;      // dim rounded up to 64
+    uint32_t k_pad;      // dim rounded up to 128
     uint32_t KS;         // k_pad / 16 fragment k-steps
-    uint32_t variant;    // prefilter kernel, see mfma_geometry()
-    uint32_t wm;         // waves along M (2 or 4)
-    uint32_t wave_rows;  // rows per wave tile (64 or 128): workgroup tile = wave_rows*wm rows
-    uint32_t tile_queries; // queries per workgroup tile (128 or 256)
-    uint32_t unit_rows;  // rows per 1 KiB mirror unit: 32 (32x32x16 MFMA operands) or 16 (16x16x32)
-    uint32_t lists_per_strip;
-    uint32_t cand_layout; // how a candidate's low mantissa bits + list map back to a row (cand_row)
-    uint32_t n_rowtiles; // ceil(n_rows / (wave_rows*wm))
-    uint32_t strip_tiles; // row tiles per strip (1..32)
+    uint32_t n_rowtiles; // ceil(n_rows / 256)
+    uint32_t strip_tiles; // row tiles per strip (1..16)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
-    uint32_t n_lists;    // candidate lists per query = 2 * wm * n_strips
-    size_t mirror_bytes; // bf16 mirror of the corpus
+    uint32_t n_lists;    // candidate lists per query = 4 * n_strips
+    size_t mirror_bytes; // bf16 mirror of the corpus (rows padded to 256)
 };
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t variant);
-float mfma_epsilon(uint32_t k_pad);
+constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor assumes K <= 32768
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim);
+float mfma_f32_slack(uint32_t k_pad);
 
 struct MfmaRescoreArgs {
     const uint4 *corpus;
@@ -118,25 +112,27 @@ struct MfmaRescoreArgs {
     vfsx_hit *out;        // [nq][k]
     int *flags;           // [nq] 1 = not verified, re-run exactly
     uint32_t n_rows, d_chunks, q_stride, k, kp;
-    float eps;
+    const float *q_eps;   // [nq] eps_q of mfma_query_prep_kernel
     uint64_t row_base, id_base;
-    uint32_t strip_tiles, wm, wave_rows;
+    uint32_t strip_tiles;
     int euclid;           // 0 = Cosine, 1 = Euclidean (see vfsx_mfma.hip)
     const float *q_norm;  // [nq] the scalar each query mirror row was divided by
     float gamma;          // relative f32 error allowance of the Euclidean check
     int only_flagged;     // != 0: second pass, only queries whose flags[q] is set (they are re-decided)
 };
+// stats[2] (device): [0] != 0: a row norm outside the path's range; [1]: R_x, the mirror's largest rounding
+// residual (float bits).  Both zeroed by the caller before the two launches.
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
-                              uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
-                              uint32_t n_rowgroups, uint32_t unit_rows, int *bad_flag, hipStream_t s);
+                              uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, const MfmaGeometry &g,
+                              uint32_t *stats, hipStream_t s);
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                  uint32_t unit_rows, int *q_bad, float *q_norm, hipStream_t s);
+                                  int *q_bad, float *q_norm, float *q_eps, const uint32_t *stats, hipStream_t s);
 // out[n_pad] float2 = (b, b^2 (1 - gamma)), zero beyond n_rows
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
                                      hipStream_t s);
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
-                                 const float *q_norm, float eps_e, hipStream_t s);
+                                 const float *q_norm, const float *q_eps, hipStream_t s);
 // only_flagged != nullptr: skip queries whose flag is 0
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
                               const int *only_flagged, hipStream_t s);

@@ -1,5 +1,5 @@
 // vfsx_mfma.hip -- many-query batches (BASELINE config C4) as a dense contraction
-// Q . X^T on the CDNA4 matrix cores, with a fused per-lane top-2 epilogue, followed by
+// Q . X^T on the CDNA4 matrix cores, with a fused per-lane top-3 epilogue, followed by
 // an EXACT sequential-order re-score of the surviving candidates and a rigorous check
 // that no row outside them can belong to the reference's top-k.
 //
@@ -17,9 +17,10 @@
 //   select   per query: the kp best approximate scores over all lists  -> sel[q][kp]
 //   rescore  per query: exact sequential f32 distance (the scan's arithmetic) of the kp
 //            rows, exact top-k by (distance, row), and the safety check:
-//              every row NOT re-scored has  s~ < c_k - eps,  c_k = 1 - (k-th exact distance)
-//            with eps bounding |s~ - cos_reference| (see mfma_epsilon()).  A query that
-//            fails it is flagged and re-run by the exact scan (host side).
+//              every row NOT re-scored has  s~ < c_k - eps_q,  c_k = 1 - (k-th exact distance)
+//            with eps_q bounding |s~ - cos_reference| for this query against EVERY row (the error
+//            model at the end of this file: the mirrors' measured bf16 rounding residuals, not a
+//            typical-case figure).  A query that fails it is flagged and re-run by the exact scan.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,10 +39,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr uint32_t kTileQueries = 128;   // queries per workgroup tile (N)
-constexpr uint32_t kMaxStripTiles = 32;  // row tiles per strip (runtime, <= 32): up to 4096 rows share one top-2 per lane
+constexpr uint32_t kMaxStripTiles = 16;  // 256-row tiles per strip (runtime): up to 4096 rows share one top-3 per lane
 constexpr uint32_t kListDepth = 3;       // scores kept per candidate list
-constexpr uint32_t kIdxBits = 10;        // 5 bits tile-in-strip, 1 bit mi, 4 bits accumulator register
+constexpr uint32_t kIdxBits = 10;        // 4 bits tile-in-strip, 2 bits mi, 4 bits accumulator register
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f)
@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f)
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-// The batch path's error bounds (mfma_epsilon, gamma) are RELATIVE f32 bounds: they hold while no product or
+// The batch path's f32 error terms (mfma_f32_slack, gamma) are RELATIVE f32 bounds: they hold while no product or
 // sum the reference forms is subnormal or overflows.  Norms inside [2^-30, 2^30] guarantee that for everything
 // that matters (a term that still underflows is below 2^-89 of the result's scale).  A row outside the range
 // (or with a zero / non-finite norm) disables the path for the corpus, a query outside it goes to the exact scan.
@@ -60,11 +60,12 @@ __device__ __forceinline__ bool norm_in_mfma_range(float n) { return n >= 0x1p-3
 // unit (g, s) = 1 KiB: lane l holds row 32g + (l & 31), k = 16s + 8(l >> 5) .. +7 -- exactly
 // the A/B operand of v_mfma_f32_32x32x16_bf16, so staging is a linear copy and every
 // fragment read is a conflict-free lane-linear ds_read_b128.
+// stats[0]: set when a row's norm is outside the path's range; stats[1]: see mfma_residual_kernel.
 template <int DTYPE>
 __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
                                    const float *__restrict__ lut, uint4 *__restrict__ mirror, uint32_t n_rows,
                                    uint32_t dim, uint32_t d_chunks, uint32_t KS, uint64_t total_units,
-                                   int *__restrict__ bad_flag, uint32_t unit_rows)
+                                   uint32_t *__restrict__ stats)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t unit = t >> 6;
@@ -72,17 +73,15 @@ __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float
         return;
     const uint32_t lane = (uint32_t)(t & 63u);
     const uint32_t g = (uint32_t)(unit / KS), s = (uint32_t)(unit % KS);
-    // unit = unit_rows x (512 / unit_rows) bf16: 32 x 16 (v_mfma_f32_32x32x16_bf16 operands) or
-    // 16 x 32 (v_mfma_f32_16x16x32_bf16); lane l <-> row l % unit_rows, 8 consecutive k from 8 (l / unit_rows)
-    const uint32_t row = g * unit_rows + (lane % unit_rows);
-    const uint32_t k0 = s * (512u / unit_rows) + (lane / unit_rows) * 8u;
+    const uint32_t row = g * 32u + (lane & 31u);
+    const uint32_t k0 = s * 16u + (lane >> 5) * 8u;
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < n_rows) {
         const float n2 = row_norms[row];
         const bool ok = norm_in_mfma_range(n2);
         if (!ok) {
-            if (s == 0 && lane < unit_rows)
-                atomicOr(bad_flag, 1);
+            if (s == 0 && lane < 32u)
+                atomicOr(&stats[0], 1u);
         } else {
             const uint8_t *base = (const uint8_t *)(corpus + (size_t)(row >> 6) * d_chunks * 64u + (row & 63u));
 #pragma unroll
@@ -103,6 +102,61 @@ __global__ void mfma_mirror_kernel(const uint4 *__restrict__ corpus, const float
                                            h[6] | (h[7] << 16));
 }
 
+// What the bf16 rounding did to one mirrored element: y = fl(x / n) is what was rounded, y - bf16(y) is
+// exactly representable in f32 (the low bits of y), so the residual is measured, not estimated.
+__device__ __forceinline__ float bf16_residual(float y)
+{
+    return y - __uint_as_float(f32_to_bf16_rne(y) << 16);
+}
+// upper bound of || x/n - mirror(x) ||_2 from the f32 sum of the squared residuals of `K` elements: the sum
+// and the sqrt lose at most (K/2 + 2) 2^-24 of it, and y itself is within 2^-24 of x/n per element
+__device__ __forceinline__ float residual_norm_bound(float sum_sq, uint32_t K)
+{
+    return __builtin_sqrtf(sum_sq) * (1.0f + ((float)K + 8.0f) * 0x1p-24f) + 0x1p-23f;
+}
+
+// ---- mirror residual: R_x = max over rows of || x/b - x~ ||_2 (error model at the end of the file) ------
+// One thread per row, walking its chunks like row_norms_kernel; the wave's maximum goes to stats[1] by an
+// integer atomicMax on the float's bits (non-negative floats order like their bit patterns).
+template <int DTYPE>
+__global__ void mfma_residual_kernel(const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
+                                     const float *__restrict__ lut, uint32_t n_rows, uint32_t d_chunks, uint32_t K,
+                                     uint32_t *__restrict__ stats)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    float r = 0.0f;
+    if (row < n_rows) {
+        const float n2 = row_norms[row];
+        if (norm_in_mfma_range(n2)) {
+            const uint4 *p = corpus + (size_t)(row >> 6) * d_chunks * 64u + (row & 63u);
+            float acc = 0.0f;
+            for (uint32_t c = 0; c < d_chunks; ++c) {
+                const uint4 v = p[(size_t)c * 64u];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                if (DTYPE == VFSX_I8) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float d = bf16_residual(lut[(w[e >> 2] >> (8 * (e & 3))) & 0xffu] / n2);
+                        acc += d * d;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = bf16_residual(__uint_as_float(w[e]) / n2);
+                        acc += d * d;
+                    }
+                }
+            }
+            r = residual_norm_bound(acc, K);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        r = fmaxf(r, __shfl_xor(r, o, 64));
+    if ((threadIdx.x & 63u) == 0u && r > 0.0f)
+        atomicMax(&stats[1], __float_as_uint(r));
+}
+
 // ---- Euclidean batches: per-row (b, b^2 (1 - gamma)) with b = the f32 row norm the mirror used ----
 __global__ void mfma_rownorm_pairs_kernel(const float *__restrict__ row_norms, uint32_t n_rows, uint32_t n_pad,
                                           float gamma, float2 *__restrict__ out)
@@ -119,9 +173,13 @@ __global__ void mfma_rownorm_pairs_kernel(const float *__restrict__ row_norms, u
 }
 
 // ---- query prep: one wave per query -------------------------------------------------------
+// Writes the query's mirror row, its norm a, and eps_q >= |s~ - q.x / (a b)| for every row x of the corpus
+// (error model at the end of the file): (R_x + r_q)(1 + 2^-7) + f32 slack, with r_q this query's own measured
+// rounding residual and R_x = stats[1] the mirror's.
 __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
                                        uint16_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad,
-                                       float *__restrict__ q_norm, uint32_t unit_rows)
+                                       float *__restrict__ q_norm, float *__restrict__ q_eps,
+                                       const uint32_t *__restrict__ stats, float f32_slack)
 {
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -134,42 +192,30 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
         s += __shfl_xor(s, o, 64);
     const float n1 = __builtin_sqrtf(s);
     const bool ok = norm_in_mfma_range(n1);
+    float res = 0.0f;
+    if (ok) {
+        for (uint32_t k = lane; k < dim; k += 64) {
+            const uint32_t unit = (q >> 5) * KS + (k >> 4);
+            const uint32_t l2 = (q & 31u) + 32u * ((k & 15u) >> 3);
+            const float y = src[k] / n1;
+            q_mirror[((size_t)unit * 64u + l2) * 8u + (k & 7u)] = (uint16_t)f32_to_bf16_rne(y);
+            const float d = bf16_residual(y);
+            res += d * d;
+        }
+    } // else: the mirror row stays zero (memset by the host) and the query takes the exact scan
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        res += __shfl_xor(res, o, 64);
     if (lane == 0) {
         q_bad[q] = ok ? 0 : 1;
         q_norm[q] = ok ? n1 : 0.0f; // the scalar the mirror row was divided by (Euclidean epilogue + check)
-    }
-    if (!ok)
-        return; // mirror stays zero (memset by the host)
-    for (uint32_t k = lane; k < dim; k += 64) {
-        const uint32_t unit_k = 512u / unit_rows; // see mfma_mirror_kernel
-        const uint32_t unit = (q / unit_rows) * KS + (k / unit_k);
-        const uint32_t l2 = (q % unit_rows) + unit_rows * ((k % unit_k) >> 3);
-        q_mirror[((size_t)unit * 64u + l2) * 8u + (k & 7u)] = (uint16_t)f32_to_bf16_rne(src[k] / n1);
+        const float r_q = residual_norm_bound(res, KS * 16u);
+        const float r_x = __uint_as_float(stats[1]);
+        q_eps[q] = (r_x + r_q) * (1.0f + 0x1p-7f) + f32_slack;
     }
 }
 
 // ---- prefilter GEMM ---------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const uint4 *g, uint4 *lds_wave_base)
-{
-    // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane * 16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
-// Same, with the LDS destination laundered through an empty asm so that hipcc cannot tell which
-// __shared__ object the DMA writes.  Its waitcnt pass orders every ds_read of an object behind the
-// pending LDS-DMAs it can attribute to that object -- and, unable to count them in order, does so
-// with s_waitcnt vmcnt(0), i.e. it drains the whole ring once per unrolled round and serialises the
-// freshly issued stage with the MFMAs.  The ring's own protocol (counted vmcnt + s_barrier before a
-// slot is read, barrier before it is refilled) is what makes the reads safe, not the compiler's.
-__device__ __forceinline__ void glds16_untracked(const uint4 *g, uint4 *lds_wave_base)
-{
-    uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base;
-    asm volatile("" : "+v"(a));
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)(uintptr_t)a, 16, 0, 0);
-}
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 frag_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -183,189 +229,32 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
     return c.b;
 }
 
-// grid = n_strips * n_qtiles workgroups of 128*WM threads: 2*WM waves as WM(M) x 2(N), 64x64 per
-// wave, i.e. a (64*WM rows) x 128 queries tile.  K runs in steps of 64 through an NSTAGE-deep ring of
-// LDS buffers filled by global_load_lds: stage it+NSTAGE-1 is issued right after the barrier that
-// opens iteration `it`, a counted s_waitcnt vmcnt leaves NSTAGE-2 stages in flight across the (raw)
-// barrier, so HBM/L2 latency is covered by NSTAGE-1 K-steps of MFMA work instead of one.
-template <int WM, int NSTAGE>
-__global__ __launch_bounds__(128 * WM) void mfma_prefilter_kernel(const uint4 *__restrict__ A,
-                                                                  const uint4 *__restrict__ B,
-                                                                  float *__restrict__ cand, uint32_t n_rows,
-                                                                  uint32_t n_rowtiles, uint32_t KS,
-                                                                  uint32_t n_qtiles, uint32_t nq, uint32_t n_lists,
-                                                                  uint32_t strip_tiles)
-{
-    constexpr uint32_t WAVES = 2u * WM, TROWS = 64u * WM;
-    constexpr uint32_t A_UNITS = (TROWS / 32u) * 4u, B_UNITS = 16u, UNITS = A_UNITS + B_UNITS;
-    constexpr uint32_t G = UNITS / WAVES; // global_load_lds instructions per wave and stage
-    static_assert(UNITS % WAVES == 0, "stage units must split evenly over the waves");
-    // One __shared__ object per ring slot (WM=2: 2 x 32 KiB; WM=4: 3 x 48 KiB), and the K loop below is
-    // unrolled NSTAGE times so every slot index is a compile-time constant: hipcc orders a ds_read
-    // behind every LDS-DMA it cannot prove disjoint, i.e. with one dynamically indexed array it
-    // drains the whole ring (s_waitcnt vmcnt(0)) before the first fragment read of each K-step.
-    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
-    __shared__ __align__(16) uint4 lds_s0[UNITS * 64];
-    __shared__ __align__(16) uint4 lds_s1[UNITS * 64];
-    __shared__ __align__(16) uint4 lds_s2[NSTAGE == 3 ? UNITS * 64 : 4];
-    auto slot = [&](int j) -> uint4 * { return j == 0 ? lds_s0 : (j == 1 ? lds_s1 : lds_s2); };
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t wave_m = wave >> 1, wave_n = wave & 1u;
-
-    // XCD-aware mapping (speed only).  Workgroups with equal id % 8 share an XCD and its 4 MiB L2.
-    // Give each XCD a fixed slice of the query tiles (its share of Q~ then stays L2-resident) and let
-    // it walk the row strips in order; all XCDs walk the strips at the same pace, so a strip fetched
-    // by one XCD is served to the others from the Infinity Cache.  Needs n_qtiles % 8 == 0;
-    // otherwise fall back to consecutive tiles per XCD (bijective remap).
-    const uint32_t total = gridDim.x;
-    const uint32_t id = blockIdx.x, xcd = id & 7u;
-    uint32_t strip, qtile;
-    if ((n_qtiles & 7u) == 0u) {
-        const uint32_t qpx = n_qtiles >> 3, within = id >> 3;
-        strip = within / qpx;
-        qtile = xcd * qpx + within % qpx;
-    } else {
-        const uint32_t q8 = total >> 3, r8 = total & 7u;
-        const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
-        strip = t / n_qtiles;
-        qtile = t % n_qtiles;
-    }
-    const uint32_t tile0 = strip * strip_tiles;
-    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
-    const uint32_t KT = KS >> 2;
-    const uint32_t n_it = ntiles * KT;
-
-    auto stage = [&](uint32_t it, uint4 *dst) {
-        const uint32_t tile = tile0 + it / KT, kt = it % KT;
-#pragma unroll
-        for (uint32_t u = 0; u < G; ++u) {
-            const uint32_t unit = wave * G + u; // wave-uniform
-            if (unit < A_UNITS) {
-                const uint32_t rg = unit >> 2, ks = unit & 3u;
-                glds16(A + ((size_t)(tile * (TROWS / 32u) + rg) * KS + kt * 4u + ks) * 64u + lane,
-                       dst + unit * 64u);
-            } else {
-                const uint32_t ub = unit - A_UNITS, qg = ub >> 2, ks = ub & 3u;
-                glds16(B + ((size_t)(qtile * 4u + qg) * KS + kt * 4u + ks) * 64u + lane, dst + unit * 64u);
-            }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[mi][ni][r] = 0.0f;
-    const float ninf = __uint_as_float(0xff800000u);
-    float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf}; // running top-3 per query column
-
-
-    // one K-step on ring slot J (compile-time): retire stage `it`, barrier, refill the slot freed by
-    // iteration it-1 with stage it+NSTAGE-1, then 16 MFMAs on slot J
-    auto kstep = [&](auto jc, uint32_t it) {
-        constexpr int J = decltype(jc)::value;
-        constexpr int JW = (J + NSTAGE - 1) % NSTAGE;
-        const uint4 *rd = slot(J);
-        // retire stage `it` (this wave's part), leaving the younger stages in flight
-        if (NSTAGE > 2 && it + (NSTAGE - 2) < n_it) {
-            if (G * (NSTAGE - 2) == 6)
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (G * (NSTAGE - 2) == 8)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier(); // every wave's part of stage `it` has landed; slot JW is free
-        if (it + (NSTAGE - 1) < n_it)
-            stage(it + (NSTAGE - 1), slot(JW));
-#pragma unroll
-        for (uint32_t ks = 0; ks < 4; ++ks) {
-            const bf16x8 a0 = as_bf16x8(rd[((wave_m * 2u + 0u) * 4u + ks) * 64u + lane]);
-            const bf16x8 a1 = as_bf16x8(rd[((wave_m * 2u + 1u) * 4u + ks) * 64u + lane]);
-            const bf16x8 b0 = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + 0u) * 4u + ks) * 64u + lane]);
-            const bf16x8 b1 = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + 1u) * 4u + ks) * 64u + lane]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (it % KT == KT - 1u) {
-            // tile finished: fold its 64 scores per lane into the running top-3 of each query column.
-            // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-            const uint32_t ts = it / KT;
-            const uint32_t tile_row0 = (tile0 + ts) * TROWS;
-            const bool ragged = tile_row0 + TROWS > n_rows;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t idx = (ts << 5) | ((uint32_t)mi << 4) | (uint32_t)r;
-                        float sp = __uint_as_float((__float_as_uint(acc[mi][ni][r]) & ~kIdxMask) | idx);
-                        if (ragged) {
-                            const uint32_t row = tile_row0 + wave_m * 64u + (uint32_t)mi * 32u + ((uint32_t)r & 3u) +
-                                                 8u * ((uint32_t)r >> 2) + 4u * (lane >> 5);
-                            if (row >= n_rows)
-                                sp = ninf;
-                        }
-                        // insert sp into the sorted triple (m1 >= m2 >= m3) in 3 VALU ops: with a >= b,
-                        // med3(a, b, s) is what b becomes when s is inserted above or below it
-                        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
-                        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
-                        m1[ni] = fmaxf(m1[ni], sp);
-                        acc[mi][ni][r] = 0.0f;
-                    }
-        }
-    };
-
-    if (0 < n_it)
-        stage(0, slot(0));
-    if (NSTAGE == 3 && 1 < n_it)
-        stage(1, slot(1));
-    for (uint32_t it = 0; it < n_it; it += NSTAGE) {
-        kstep(std::integral_constant<int, 0>{}, it);
-        if (it + 1 < n_it)
-            kstep(std::integral_constant<int, 1>{}, it + 1);
-        if (NSTAGE == 3 && it + 2 < n_it)
-            kstep(std::integral_constant<int, 2>{}, it + 2);
-    }
-
-    const uint32_t list = strip * (2u * WM) + wave_m * 2u + (lane >> 5);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const uint32_t q = qtile * kTileQueries + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
-        if (q < nq) {
-            cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
-            cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
-            cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
-        }
-    }
-}
-
-// ---- prefilter GEMM, 256 rows x 256 queries per workgroup (the default) ---------------------------
-// The 256 x 128 kernel above moves (256+128) x 2 B per 2 x 256 x 128 flop of K-slice through
-// L2 -> LDS = 85 flop/B, and at ~0.9 PFLOP/s that is ~11 TB/s of global_load_lds traffic -- the
-// same figure the 128 x 128 tile (64 flop/B, 0.72 PFLOP/s) hit: both are bound by the L2 -> LDS
-// fill rate, not by the matrix cores.  This tile raises it to 128 flop/B: 8 waves as 2 (M) x 4 (N),
-// 128 rows x 64 queries per wave (4 x 2 MFMA tiles, 128 accumulator registers), 6 fragment reads
-// per 8 MFMAs.  K runs in steps of 16*KU through an NSTAGE-deep ring (KU=2: 4 x 32 KiB,
-// KU=4: 2 x 64 KiB), same counted-vmcnt protocol as above.
+// ---- prefilter GEMM, 256 rows x 256 queries per workgroup ------------------------------------------
+// 8 waves as 2 (M) x 4 (N), 128 rows x 64 queries per wave (4 x 2 MFMA tiles, 128 accumulator registers),
+// 6 fragment reads per 8 MFMAs: 128 flop per byte moved L2 -> LDS.  (Round 1 measured a 128 x 128 tile,
+// 64 flop/B, at 0.72 PFLOP/s and a 256 x 128 tile, 85 flop/B, at 0.9: both sat at ~11 TB/s of LDS fill,
+// not at the matrix cores; those kernels and a 16x16x32-MFMA twin of this one, which measured the same as
+// this one, were removed in round 2.)  K runs in steps of 16*KU through an NSTAGE-deep ring of LDS slots
+// (KU=4: 2 x 64 KiB) filled by buffer_load ... lds: the stage for K-step it+NSTAGE-1 is issued during K-step
+// `it`, a counted s_waitcnt vmcnt leaves NSTAGE-2 stages in flight across the (raw) barrier.
+//
+// Two compiler facts are load-bearing.  hipcc's waitcnt pass orders every ds_read of a __shared__ object
+// behind the pending LDS-DMAs it can attribute to that object and, unable to count them in order, does so
+// with s_waitcnt vmcnt(0) -- draining the ring once per unrolled round and serialising the freshly issued
+// stage with the MFMAs.  So (1) every DMA's LDS destination is laundered through an empty asm (the compiler
+// cannot tell which object it writes), and (2) there is one __shared__ object per ring slot and the K loop is
+// unrolled NSTAGE times so that every slot index is a compile-time constant.  The ring's own protocol (counted
+// vmcnt + s_barrier before a slot is read, barrier before it is refilled) is what makes the reads safe.
+//
 // Candidate lists: list = strip * 4 + wave_m * 2 + (lane >> 5); row position in the 10 low
 // mantissa bits = tile-in-strip (4 bits) | mi (2 bits) | accumulator register (4 bits).
 //
 // MODE 0 (Cosine): the candidate score is s~ itself.  MODE 1 (Euclidean): the same contraction, but
 // the epilogue turns s~ into an UPPER bound of  V = 2 q.x - ||x||^2  (D^2 = ||q||^2 - V, so larger V =
-// closer):  key = 2a * (b * (s~ + eps_e)) - b^2 (1 - gamma), a / b = the norms the two mirrors were
-// divided by, eps_e >= |s~ - q.x / (a b)|, gamma covering the f32 error of b^2 vs ||x||^2 and of the
-// three roundings here.  rn2[row] = (b, b^2 (1 - gamma)).
+// closer):  key = 2a * (b * (s~ + eps_q)) - b^2 (1 - gamma), a / b = the norms the two mirrors were
+// divided by, eps_q >= |s~ - q.x / (a b)| per query (q_eps, written by mfma_query_prep_kernel), gamma
+// covering the f32 error of b^2 vs ||x||^2; the three roundings here are covered by the surplus f32 slack
+// inside eps_q (error model at the end of the file).  rn2[row] = (b, b^2 (1 - gamma)).
 template <int KU, int NSTAGE, int MODE>
 __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__restrict__ A,
                                                                 const uint4 *__restrict__ B,
@@ -373,7 +262,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                                                                 uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
                                                                 uint32_t nq, uint32_t n_lists, uint32_t strip_tiles,
                                                                 const float2 *__restrict__ rn2,
-                                                                const float *__restrict__ q_norm, float eps_e)
+                                                                const float *__restrict__ q_norm,
+                                                                const float *__restrict__ q_eps)
 {
     constexpr uint32_t TROWS = 256u, TQ = 256u;
     constexpr uint32_t A_UNITS = 8u * KU, UNITS = 16u * KU;
@@ -390,7 +280,11 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
     const uint32_t wave_m = wave >> 2, wave_n = wave & 3u;
 
-    // XCD-aware mapping: see mfma_prefilter_kernel
+    // XCD-aware mapping (speed only).  Workgroups with equal id % 8 share an XCD and its 4 MiB L2.
+    // Give each XCD a fixed slice of the query tiles (its share of Q~ then stays L2-resident) and let
+    // it walk the row strips in order; all XCDs walk the strips at the same pace, so a strip fetched
+    // by one XCD is served to the others from the Infinity Cache.  Needs n_qtiles % 8 == 0;
+    // otherwise fall back to consecutive tiles per XCD (bijective remap).
     const uint32_t total = gridDim.x;
     const uint32_t id = blockIdx.x, xcd = id & 7u;
     uint32_t strip, qtile;
@@ -444,7 +338,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         }
     };
     auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t koff, uint32_t slot_base, uint32_t u) {
-        // LDS destination laundered: see glds16_untracked
+        // LDS destination laundered (see the kernel's header comment)
         uint32_t a = slot_base + pc_lds[u];
         asm volatile("" : "+s"(a));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
@@ -474,12 +368,13 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     uint32_t keep_mask = ~kIdxMask;
     asm volatile("" : "+v"(keep_mask)); // keep it in a VGPR (see the epilogue)
     uint32_t cur_kt = 0, cur_ts = 0;    // position of the running K-step inside the strip
-    float cq[2] = {0.0f, 0.0f}; // MODE 1: 2a per query column
+    float cq[2] = {0.0f, 0.0f}, ce[2] = {0.0f, 0.0f}; // MODE 1: 2a and eps_q per query column
     if (MODE == 1) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
             cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
+            ce[ni] = q < nq ? q_eps[q] : 0.0f;
         }
     }
 
@@ -509,7 +404,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                     for (int ni = 0; ni < 2; ++ni) {
                         float v = acc[mi][ni][r];
                         if (MODE == 1)
-                            v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
+                            v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
                         float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
                         if (RAGGED && row4 + (uint32_t)rl >= n_rows)
                             sp = ninf;
@@ -627,7 +522,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                                                                     uint32_t n_rowtiles, uint32_t KS, uint32_t nq,
                                                                     uint32_t n_lists, uint32_t strip_tiles,
                                                                     const float2 *__restrict__ rn2,
-                                                                    const float *__restrict__ q_norm, float eps_e)
+                                                                    const float *__restrict__ q_norm,
+                                                                    const float *__restrict__ q_eps)
 {
     constexpr uint32_t KU = 4u, TROWS = 256u;
     // NCOL = 64-query columns per workgroup (1: <= 64 queries, 2: <= 128): 32 row units + 8 NCOL query units of
@@ -662,7 +558,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
 #pragma unroll
         for (uint32_t u = 0; u < KU; ++u) {
             uint32_t a = slot_base + a_lds + u * 1024u;
-            asm volatile("" : "+s"(a)); // LDS destination laundered: see glds16_untracked
+            asm volatile("" : "+s"(a)); // LDS destination laundered: see mfma_prefilter256_kernel
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
                                                      (int)lane16, (int)(a_soff + u * 1024u + nx_koff), 0, 0);
         }
@@ -697,15 +593,16 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
         m1[ni] = m2[ni] = m3[ni] = ninf;
     uint32_t keep_mask = ~kIdxMask;
     asm volatile("" : "+v"(keep_mask));
-    float cq[NI]; // MODE 1: 2a per query column
+    float cq[NI], ce[NI]; // MODE 1: 2a and eps_q per query column
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
-        cq[ni] = 0.0f;
+        cq[ni] = ce[ni] = 0.0f;
     if (MODE == 1) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
             cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
+            ce[ni] = q < nq ? q_eps[q] : 0.0f;
         }
     }
     auto insert3 = [&](int ni, float sp) __attribute__((always_inline)) {
@@ -733,7 +630,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                 for (int ni = 0; ni < NI; ++ni) {
                     float v = acc[ni][r];
                     if (MODE == 1)
-                        v = cq[ni] * (bn[rl] * (v + eps_e)) - bs[rl];
+                        v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
                     float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
                     if (ragged && row4 + (uint32_t)rl >= n_rows)
                         sp = ninf;
@@ -853,214 +750,6 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
     }
 }
 
-// ---- prefilter GEMM on v_mfma_f32_16x16x32_bf16 (variant 4) ------------------------------------------
-// Same 256 x 256 tile, 8 waves as 2 (M) x 4 (N), 128 rows x 64 queries per wave, BK = 64 in a 2-slot
-// ring, same staging / barrier protocol and bookkeeping as mfma_prefilter256_kernel -- but the
-// contraction runs on the 16x16x32 MFMA shape (32 per 32-wide k-slice instead of 8 per 16-wide one; the
-// guide measures it ~1.15x the FLOP/s of 32x32x16 at equal cycles because the chip holds a higher clock
-// on it).  The mirrors are then laid out in 16-row x 32-k units (lane l <-> row l & 15, k = 8 (l >> 4)..).
-// C/D: column (query) = lane & 15, row = 4 (lane >> 4) + reg.  A lane therefore sees 32 rows of a tile
-// (8 mi x 4 regs) for each of its 4 query columns; candidate lists: list = strip * 8 + wave_m * 4 +
-// (lane >> 4), up to 32 tiles (8192 rows) per strip, index = tile-in-strip (5 bits) | mi (3) | reg (2).
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-template <int MODE>
-__global__ __launch_bounds__(512) void mfma_prefilter256x_kernel(const uint4 *__restrict__ A,
-                                                                 const uint4 *__restrict__ B,
-                                                                 float *__restrict__ cand, uint32_t n_rows,
-                                                                 uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
-                                                                 uint32_t nq, uint32_t n_lists, uint32_t strip_tiles,
-                                                                 const float2 *__restrict__ rn2,
-                                                                 const float *__restrict__ q_norm, float eps_e)
-{
-    constexpr uint32_t TROWS = 256u, TQ = 256u;
-    constexpr uint32_t KU = 2u;                         // 32-wide k-slices per K-step (BK = 64)
-    constexpr uint32_t A_UNITS = 16u * KU, UNITS = 32u * KU; // 16-row units: 16 row groups + 16 query groups
-    constexpr uint32_t G = UNITS / 8u;                  // 8 pieces per wave and stage
-    __shared__ __align__(16) uint4 lds_s0[UNITS * 64];
-    __shared__ __align__(16) uint4 lds_s1[UNITS * 64];
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
-    const uint32_t wave_m = wave >> 2, wave_n = wave & 3u;
-
-    // XCD-aware mapping: see mfma_prefilter_kernel
-    const uint32_t total = gridDim.x;
-    const uint32_t id = blockIdx.x, xcd = id & 7u;
-    uint32_t strip, qtile;
-    if ((n_qtiles & 7u) == 0u) {
-        const uint32_t qpx = n_qtiles >> 3, within = id >> 3;
-        strip = within / qpx;
-        qtile = xcd * qpx + within % qpx;
-    } else {
-        const uint32_t q8 = total >> 3, r8 = total & 7u;
-        const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
-        strip = t / n_qtiles;
-        qtile = t % n_qtiles;
-    }
-    const uint32_t tile0 = strip * strip_tiles;
-    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
-    const uint32_t KT = KS / KU;
-    const uint32_t n_it = ntiles * KT;
-
-    // staging and bookkeeping: as in mfma_prefilter256_kernel (waves 0-3: row units, 4-7: query units)
-    const bool a_wave = wave < 4u;
-    const uint32_t lane16 = lane * 16u;
-    uint32_t pc_soff[G], pc_lds[G];
-#pragma unroll
-    for (uint32_t u = 0; u < G; ++u) {
-        const uint32_t unit = (wave & 3u) * G + u; // 0 .. 31
-        const uint32_t grp = unit / KU, ks = unit % KU;
-        pc_soff[u] = (grp * KS + ks) * 1024u;
-        pc_lds[u] = ((a_wave ? 0u : A_UNITS) + unit) * 1024u;
-    }
-    const uint32_t tile_bytes = 16u * KS * 1024u; // one 256-row tile of the mirror
-    uintptr_t nx_base = a_wave ? (uintptr_t)A + (uintptr_t)tile0 * tile_bytes : (uintptr_t)B + (uintptr_t)qtile * tile_bytes;
-    uint32_t nx_idx = 0, nx_koff = 0;
-    auto next_rsrc = [&]() -> __amdgpu_buffer_rsrc_t {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, 0xffffffff, 0x00020000);
-    };
-    auto advance = [&]() {
-        if (nx_idx + 1u < n_it) {
-            ++nx_idx;
-            nx_koff += KU * 1024u;
-            if (nx_koff == KS * 1024u) {
-                nx_koff = 0;
-                if (a_wave)
-                    nx_base += tile_bytes;
-            }
-        }
-    };
-    auto stage_piece = [&](__amdgpu_buffer_rsrc_t rsrc, uint32_t koff, uint32_t slot_base, uint32_t u) {
-        uint32_t a = slot_base + pc_lds[u]; // laundered: see glds16_untracked
-        asm volatile("" : "+s"(a));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
-                                                 (int)lane16, (int)(pc_soff[u] + koff), 0, 0);
-    };
-    auto lds_addr = [&](uint4 *p) -> uint32_t {
-        return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)p;
-    };
-
-    f32x4v acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const float ninf = __uint_as_float(0xff800000u);
-    float m1[4], m2[4], m3[4], cq[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        m1[ni] = m2[ni] = m3[ni] = ninf;
-        cq[ni] = 0.0f;
-        if (MODE == 1) {
-            const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 16u + (lane & 15u);
-            cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
-        }
-    }
-    uint32_t keep_mask = ~kIdxMask;
-    asm volatile("" : "+v"(keep_mask));
-    uint32_t cur_kt = 0, cur_ts = 0;
-
-    auto fold_tile = [&](auto ragged_c, uint32_t ts, uint32_t tile_row0) __attribute__((always_inline)) {
-        constexpr bool RAGGED = decltype(ragged_c)::value;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            // accumulator registers 0..3 of tile mi are 4 consecutive rows
-            const uint32_t row4 = tile_row0 + wave_m * 128u + (uint32_t)mi * 16u + 4u * (lane >> 4);
-            float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == 1) {
-                const float4 p0 = *(const float4 *)(rn2 + row4);
-                const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
-                bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
-                bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t idx =
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 5) | ((uint32_t)mi << 2) | (uint32_t)r));
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    float v = acc[mi][ni][r];
-                    if (MODE == 1)
-                        v = cq[ni] * (bn[r] * (v + eps_e)) - bs[r];
-                    float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
-                    if (RAGGED && row4 + (uint32_t)r >= n_rows)
-                        sp = ninf;
-                    m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
-                    m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
-                    asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
-                    acc[mi][ni][r] = 0.0f;
-                }
-            }
-        }
-    };
-
-    auto kstep = [&](uint4 *rd_slot, uint4 *wr_slot) __attribute__((always_inline)) {
-        const uint4 *rd = rd_slot;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // 2-slot ring: the stage for this K-step has landed
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const __amdgpu_buffer_rsrc_t rsrc_n = next_rsrc();
-        const uint32_t koff_n = nx_koff;
-        const uint32_t wr = lds_addr(wr_slot);
-        advance();
-#pragma unroll
-        for (uint32_t ks = 0; ks < KU; ++ks) {
-            bf16x8 a[8], b[4];
-#pragma unroll
-            for (uint32_t mi = 0; mi < 8; ++mi)
-                a[mi] = as_bf16x8(rd[((wave_m * 8u + mi) * KU + ks) * 64u + lane]);
-#pragma unroll
-            for (uint32_t ni = 0; ni < 4; ++ni)
-                b[ni] = as_bf16x8(rd[(A_UNITS + (wave_n * 4u + ni) * KU + ks) * 64u + lane]);
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) // the next stage's 8 pieces, 4 per k-slice
-                stage_piece(rsrc_n, koff_n, wr, ks * 4u + u);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (++cur_kt == KT) {
-            const uint32_t ts = cur_ts;
-            cur_kt = 0;
-            ++cur_ts;
-            const uint32_t tile_row0 = (tile0 + ts) * TROWS;
-            if (tile_row0 + TROWS > n_rows)
-                fold_tile(std::true_type{}, ts, tile_row0);
-            else
-                fold_tile(std::false_type{}, ts, tile_row0);
-        }
-    };
-
-    { // stage 0 into slot 0
-        const __amdgpu_buffer_rsrc_t rsrc = next_rsrc();
-#pragma unroll
-        for (uint32_t u = 0; u < G; ++u)
-            stage_piece(rsrc, nx_koff, lds_addr(lds_s0), u);
-        advance();
-    }
-    // n_it is even (K % 128 == 0): straight-line rounds over the two slots
-    for (uint32_t it = 0; it < n_it; it += 2) {
-        kstep(lds_s0, lds_s1);
-        kstep(lds_s1, lds_s0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the redundant tail stage must land before the LDS is released
-
-    const uint32_t list = strip * 8u + wave_m * 4u + (lane >> 4);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 16u + (lane & 15u);
-        if (q < nq) {
-            cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
-            cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
-            cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
-        }
-    }
-}
-
 // ---- select: kp best approximate scores of one query ------------------------------------------
 // composite = key(-score) << 32 | list ; smaller = better.  One workgroup per query.
 template <typename TopK, int WAVES>
@@ -1112,26 +801,16 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
 }
 
 // ---- exact re-score + safety check ----------------------------------------------------------------
-// wave_rows = rows per wave tile: 64 (mi: 1 bit) for mfma_prefilter_kernel, 128 (mi: 2 bits) for
-// mfma_prefilter256_kernel
-__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles, uint32_t wm,
-                                             uint32_t wave_rows)
+// A candidate = (approximate score with the row position in its 10 low mantissa bits, list): the inverse of the
+// prefilter kernels' list / index assignment.
+__device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32_t strip_tiles)
 {
     const uint32_t list = (uint32_t)comp;
     score = -key_dist((uint32_t)(comp >> 32));
     const uint32_t idx = __float_as_uint(score) & kIdxMask;
-    if (wave_rows == 129u) {
-        // mfma_prefilter256x_kernel (16x16x32 MFMA): idx = ts (5 bits) | mi (3) | reg (2);
-        // list = strip * 8 + wave_m * 4 + (lane >> 4); row = tile * 256 + wave_m * 128 + mi * 16 + 4 (lane >> 4) + reg
-        const uint32_t ts = idx >> 5, mi = (idx >> 2) & 7u, r = idx & 3u;
-        const uint32_t strip = list >> 3, wave_m = (list >> 2) & 1u, g4 = list & 3u;
-        return (strip * strip_tiles + ts) * 256u + wave_m * 128u + mi * 16u + 4u * g4 + r;
-    }
-    const uint32_t mi_bits = wave_rows == 128u ? 2u : 1u;
-    const uint32_t ts = idx >> (4u + mi_bits), mi = (idx >> 4) & ((1u << mi_bits) - 1u), r = idx & 15u;
-    const uint32_t strip = list / (2u * wm), wave_m = (list % (2u * wm)) >> 1, half = list & 1u;
-    return (strip * strip_tiles + ts) * (wave_rows * wm) + wave_m * wave_rows + mi * 32u + (r & 3u) + 8u * (r >> 2) +
-           4u * half;
+    const uint32_t ts = idx >> 6, mi = (idx >> 4) & 3u, r = idx & 15u;
+    const uint32_t strip = list >> 2, wave_m = (list >> 1) & 1u, half = list & 1u;
+    return (strip * strip_tiles + ts) * 256u + wave_m * 128u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
 }
 
 template <int DTYPE, int METRIC, typename TopK>
@@ -1139,9 +818,8 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms, const float *__restrict__ queries,
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
-    uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, float eps, uint64_t row_base, uint64_t id_base,
-    uint32_t strip_tiles, uint32_t wm, uint32_t wave_rows, const float *__restrict__ q_norm, float gamma,
-    int only_flagged)
+    uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, const float *__restrict__ q_eps, uint64_t row_base,
+    uint64_t id_base, uint32_t strip_tiles, const float *__restrict__ q_norm, float gamma, int only_flagged)
 {
     if (only_flagged && flags[blockIdx.x] == 0) // second, wider pass: flagged queries only (uniform exit)
         return;
@@ -1175,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     float score = 0.0f;
     uint32_t row = 0;
     if (valid)
-        row = cand_row(comp_a, score, strip_tiles, wm, wave_rows);
+        row = cand_row(comp_a, score, strip_tiles);
     const bool in_range = valid && row < n_rows;
     if (wave * 64u < kp) { // wave-uniform: this wave has candidates
         const uint32_t r = in_range ? row : 0u;
@@ -1264,7 +942,8 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     __syncthreads();
 
     // safety check.  A row r that was not re-scored can only belong to the exact top-k if
-    // dist_r <= D_k, i.e. cos_ref(r) >= c_k = 1 - D_k, hence (|s~ - cos_ref| <= eps) s~_r >= c_k - eps.
+    // dist_r <= D_k, i.e. cos_ref(r) >= c_k = 1 - D_k, hence (|s~ - cos_ref| <= eps) s~_r >= c_k - eps, with
+    // eps = eps_q + 2^-13: the 10 low mantissa bits of a score below 2 hold the row position.
     const float dk = s_dk;
     bool bad = !(dk == dk) || !(dk < __uint_as_float(0x7f800000u)); // fewer than k exact hits / NaN
     bool above;
@@ -1278,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
         const double sc = (double)score;
         above = valid && (sc + 0x1p-12 * (sc < 0.0 ? -sc : sc) >= vk_low);
     } else {
-        const float thr = (1.0f - dk) - eps;
+        const float thr = (1.0f - dk) - (q_eps[q] + 0x1p-13f);
         above = valid && score >= thr;
     }
     // (1) rows listed but not selected score <= the worst selected one (sel is sorted, full => index kp-1)
@@ -1310,28 +989,33 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
 // ---- launchers ----------------------------------------------------------------------------------------
 
 hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_norms, const float *lut,
-                              uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, uint32_t KS,
-                              uint32_t n_rowgroups, uint32_t unit_rows, int *bad_flag, hipStream_t s)
+                              uint4 *mirror, uint32_t n_rows, uint32_t dim, uint32_t d_chunks, const MfmaGeometry &g,
+                              uint32_t *stats, hipStream_t s)
 {
-    const uint64_t total_units = (uint64_t)n_rowgroups * KS; // unit_rows-row groups, rows padded to a multiple of 256
-    const uint64_t threads = total_units * 64u;
-    const uint64_t blocks = (threads + 255) / 256;
+    const uint64_t total_units = (uint64_t)g.n_rowtiles * 8u * g.KS; // 32-row groups of the padded row count
+    const uint64_t blocks = (total_units * 64u + 255) / 256;
     if (blocks > 0x7fffffffull)
         return hipErrorInvalidValue;
-    if (dtype == VFSX_I8)
+    const dim3 res_grid((n_rows + 255u) / 256u);
+    if (dtype == VFSX_I8) {
         hipLaunchKernelGGL((mfma_mirror_kernel<VFSX_I8>), dim3((uint32_t)blocks), dim3(256), 0, s, corpus, row_norms,
-                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag, unit_rows);
-    else
+                           lut, mirror, n_rows, dim, d_chunks, g.KS, total_units, stats);
+        hipLaunchKernelGGL((mfma_residual_kernel<VFSX_I8>), res_grid, dim3(256), 0, s, corpus, row_norms, lut, n_rows,
+                           d_chunks, g.k_pad, stats);
+    } else {
         hipLaunchKernelGGL((mfma_mirror_kernel<VFSX_F32>), dim3((uint32_t)blocks), dim3(256), 0, s, corpus, row_norms,
-                           lut, mirror, n_rows, dim, d_chunks, KS, total_units, bad_flag, unit_rows);
+                           lut, mirror, n_rows, dim, d_chunks, g.KS, total_units, stats);
+        hipLaunchKernelGGL((mfma_residual_kernel<VFSX_F32>), res_grid, dim3(256), 0, s, corpus, row_norms, lut, n_rows,
+                           d_chunks, g.k_pad, stats);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                  uint32_t unit_rows, int *q_bad, float *q_norm, hipStream_t s)
+                                  int *q_bad, float *q_norm, float *q_eps, const uint32_t *stats, hipStream_t s)
 {
     hipLaunchKernelGGL(mfma_query_prep_kernel, dim3(nq), dim3(64), 0, s, d_queries, nq, dim, (uint16_t *)q_mirror, KS,
-                       q_bad, q_norm, unit_rows);
+                       q_bad, q_norm, q_eps, stats, mfma_f32_slack(KS * 16u));
     return hipGetLastError();
 }
 
@@ -1343,63 +1027,42 @@ hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, ui
     return hipGetLastError();
 }
 
-// euclid != 0: Euclidean upper-bound epilogue (256 x 256 kernels only); rn2 / q_norm / eps_e as in the kernel
+// euclid != 0: Euclidean upper-bound epilogue; rn2 / q_norm / q_eps as in the kernel
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
-                                 const float *q_norm, float eps_e, hipStream_t s)
+                                 const float *q_norm, const float *q_eps, hipStream_t s)
 {
-    const uint32_t n_qtiles = (nq + g.tile_queries - 1) / g.tile_queries;
+    const uint32_t n_qtiles = (nq + 255u) / 256u;
     const dim3 grid(g.n_strips * n_qtiles);
     const uint4 *qm = (const uint4 *)q_mirror;
     const float2 *rn = (const float2 *)rn2;
-    if (euclid && g.tile_queries != 256u)
-        return hipErrorInvalidValue;
-    if (g.variant == 4u) {
-        if (euclid)
-            hipLaunchKernelGGL((mfma_prefilter256x_kernel<1>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,
-                               g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
-        else
-            hipLaunchKernelGGL((mfma_prefilter256x_kernel<0>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,
-                               g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e);
-        return hipGetLastError();
-    }
-#define VFSX_PF256(KU, NS, MODE)                                                                                   \
-    hipLaunchKernelGGL((mfma_prefilter256_kernel<KU, NS, MODE>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,   \
-                       g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e)
-    if (g.variant == 0) {
-        if (euclid)
-            VFSX_PF256(2, 4, 1);
-        else
-            VFSX_PF256(2, 4, 0);
-    } else if (g.variant == 1) {
-        // <= 64 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
-        static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
-        if (skinny_on && nq <= 128u) {
+    // <= 128 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
+    static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
+    if (skinny_on && nq <= 128u) {
 #define VFSX_SKINNY(MODE, NCOL)                                                                                    \
     hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL>), dim3(g.n_strips), dim3(512), 0, s, mirror,   \
-                       qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, eps_e)
-            if (nq <= 64u) {
-                if (euclid)
-                    VFSX_SKINNY(1, 1);
-                else
-                    VFSX_SKINNY(0, 1);
-            } else {
-                if (euclid)
-                    VFSX_SKINNY(1, 2);
-                else
-                    VFSX_SKINNY(0, 2);
-            }
+                       qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps)
+        if (nq <= 64u) {
+            if (euclid)
+                VFSX_SKINNY(1, 1);
+            else
+                VFSX_SKINNY(0, 1);
+        } else {
+            if (euclid)
+                VFSX_SKINNY(1, 2);
+            else
+                VFSX_SKINNY(0, 2);
+        }
 #undef VFSX_SKINNY
-        } else if (euclid)
-            VFSX_PF256(4, 2, 1);
-        else
-            VFSX_PF256(4, 2, 0);
-    } else if (g.wm == 4)
-        hipLaunchKernelGGL((mfma_prefilter_kernel<4, 3>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows, g.n_rowtiles,
-                           g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+        return hipGetLastError();
+    }
+#define VFSX_PF256(MODE)                                                                                           \
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2, MODE>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,     \
+                       g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps)
+    if (euclid)
+        VFSX_PF256(1);
     else
-        hipLaunchKernelGGL((mfma_prefilter_kernel<2, 2>), grid, dim3(256), 0, s, mirror, qm, cand, n_rows, g.n_rowtiles,
-                           g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles);
+        VFSX_PF256(0);
 #undef VFSX_PF256
     return hipGetLastError();
 }
@@ -1429,8 +1092,8 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
 #define VFSX_RESCORE(DT, M)                                                                                          \
     hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,           \
                        a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks,    \
-                       a.q_stride, a.k, a.kp, a.eps, a.row_base, a.id_base, a.strip_tiles, a.wm, a.wave_rows,         \
-                       a.q_norm, a.gamma, a.only_flagged)
+                       a.q_stride, a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma,       \
+                       a.only_flagged)
     if (dtype == VFSX_I8) {
         if (a.euclid)
             VFSX_RESCORE(VFSX_I8, VFSX_EUCLIDEAN);
@@ -1446,48 +1109,54 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     return hipGetLastError();
 }
 
-// variant: 0 = 256 x 256 tile, BK 32, 4-slot ring (default); 1 = 256 x 256, BK 64, 2 slots;
-//          2 = 256 x 128 (wm 4, 3 slots); 3 = 128 x 128 (wm 2, 2 slots)
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, uint32_t variant)
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim)
 {
     MfmaGeometry g;
-    g.variant = variant > 4u ? 1u : variant;
-    const bool x16 = g.variant == 4u;   // 16x16x32 MFMA, 16-row units
-    const bool t256 = g.variant <= 1u || x16;
-    g.wave_rows = t256 ? 128u : 64u;
-    g.wm = g.variant == 2u ? 4u : 2u; // waves along M
-    g.tile_queries = t256 ? 256u : 128u;
-    g.unit_rows = x16 ? 16u : 32u;
-    g.lists_per_strip = x16 ? 8u : 2u * g.wm;
-    g.cand_layout = x16 ? 129u : g.wave_rows;
-    const uint32_t tile_rows = g.wave_rows * g.wm;
-    // the 256 x 256 kernels run whole ring rounds only: K-steps per tile % ring depth == 0 <=> K % 128 == 0
-    const uint32_t k_mult = t256 ? 128u : 64u;
-    g.k_pad = (dim + k_mult - 1u) / k_mult * k_mult;
-    g.KS = g.k_pad / (512u / g.unit_rows);
-    g.n_rowtiles = (n_rows + tile_rows - 1) / tile_rows;
+    // whole ring rounds only: K-steps (of 64) per tile % ring depth (2) == 0 <=> K % 128 == 0
+    g.k_pad = (dim + 127u) / 128u * 128u;
+    g.KS = g.k_pad / 16u;
+    g.n_rowtiles = (n_rows + 255u) / 256u;
     // aim for >= ~4096 candidate lists per query so that three rows above the safety margin rarely share
     // one (small corpora get short strips -- and more workgroups); a list holds at most 1024 rows (10 index
-    // bits): 4096 rows per strip with 4 or 8 lists (32x32 MFMA), 8192 rows with 8 lists (16x16 MFMA)
-    const uint32_t max_tiles = std::min<uint32_t>(kMaxStripTiles, (x16 ? 8192u : 4096u) / tile_rows);
-    g.strip_tiles = std::min<uint32_t>(max_tiles, std::max<uint32_t>(1u, (n_rows / tile_rows) * g.lists_per_strip / 4096u));
+    // bits): at most 16 tiles = 4096 rows per strip, 4 lists per strip
+    g.strip_tiles = std::min<uint32_t>(kMaxStripTiles, std::max<uint32_t>(1u, (n_rows / 256u) * 4u / 4096u));
     g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
-    g.n_lists = g.n_strips * g.lists_per_strip;
-    g.mirror_bytes = (size_t)((n_rows + 255u) / 256u) * 256u * g.k_pad * 2u; // rows padded for either tile
+    g.n_lists = g.n_strips * 4u;
+    g.mirror_bytes = (size_t)g.n_rowtiles * 256u * g.k_pad * 2u;
     return g;
 }
 
-// |s~ - cos_reference| <= eps for every (query, row) with finite, non-zero norms:
-//   2^-8 + 2^-21  two bf16 roundings (RNE, 8-bit significand: 2^-9 each) of x/||x|| and q/||q||,
-//                 each preceded by one f32 division (2^-24), cross terms included; sum |terms| <= 1;
-//   2^-13         the 10 low mantissa bits of the score replaced by the row position;
-//   (4K+32)2^-24  f32 accumulation of K exact bf16 x bf16 products inside the MFMA (any order), plus
-//                 the reference's own f32 rounding of dot, both norms, their product, the quotient
-//                 and the final subtraction (rank.rs:291-299);
-//   2^-20         slack for flushed bf16 subnormals.
-float mfma_epsilon(uint32_t k_pad)
+// ---- error model of the prefilter score -------------------------------------------------------------------
+// Notation: x a row, q a query (their f32 elements taken as exact reals), K = k_pad, u = 2^-24.
+//   b   = the f32 row norm the scan uses (sequential sum, sqrt):   b = ||x|| (1 + e_b), |e_b| <= (K/2 + 2) u
+//   a   = the f32 query norm of mfma_query_prep_kernel (tree sum):  a = ||q|| (1 + e_a), |e_a| <= (K/2 + 2) u
+//   x^  = x / b,  q^ = q / a  (reals);   x~, q~ = the bf16 mirror rows (exact reals)
+//   s^  = x^ . q^ = q.x / (a b);         s~ = what the MFMAs accumulate from the x~_j q~_j
+// bf16 keeps 8 significand bits: ONE round-to-nearest moves a value by up to 2^-8 of itself (not 2^-9: the
+// round-1 bound had that wrong and was half of what two adversarially aligned roundings need -- a row and a
+// query whose normalised components all sit just under a bf16 midpoint lose 0.0077 of their cosine, see
+// tests/test_gpu_mfma.py::test_mfma_adversarial_bf16_midpoints).  Instead of a worst-case constant the bound
+// uses what the roundings actually did:
+//   r_x = || x^ - x~ ||_2 per row, R_x = max over the corpus (mfma_residual_kernel, stats[1]), r_q per query.
+//   Both are upper bounds: the residual of fl(x_j / b) is exact in f32, the division adds <= u |x^_j| per
+//   element, the f32 sum / sqrt are inflated by (K + 8) u (residual_norm_bound).  r <= 2^-8 (1 + 2u) always.
+// (1) s~_exact - s^ = (x~ - x^).q~ + x^.(q~ - q^):  |.| <= r_x ||q~|| + ||x^|| r_q
+//       <= r_x (1 + |e_a| + r_q) + (1 + |e_b|) r_q <= (R_x + r_q)(1 + 2^-7)          for K <= 32768
+// (2) MFMA accumulation of K exact products in f32, any order, each add rounded or truncated:
+//       |s~ - s~_exact| <= 2K u ||x~|| ||q~|| <= 2.03 K u
+//     => eps_q = (R_x + r_q)(1 + 2^-7) + mfma_f32_slack(K)  >=  |s~ - s^|   (what the Euclidean epilogue needs)
+// (3) s^ vs the true cosine c:  s^ = c / ((1 + e_a)(1 + e_b)),  |s^ - c| <= (K + 5) u
+// (4) the reference's computed cosine term c_ref = fl(dot / fl(n1 n2)) (rank.rs:291-299): sequential dot
+//     <= K u sum |q_j x_j| <= K u ||q|| ||x||, two norms (K/2 + 2) u each, product and quotient u each:
+//     |c_ref - c| <= (2K + 6) u; the final 1 - c_ref and the check's own 1 - D_k and thr roundings <= 6 u
+//     => |s~ - c_ref| <= (R_x + r_q)(1 + 2^-7) + (5.03 K + 17) u  <=  eps_q;  the Cosine check adds 2^-13 for
+//     the 10 mantissa bits of the score that hold the row position.
+// mfma_f32_slack = (6K + 64) u + 2^-20 (the last term: bf16 subnormals the MFMA may flush, < K 2^-126, and the
+// f32 roundings of eps_q's own evaluation).  The Euclidean path needs only (2) of it, 2.03 K u; the surplus
+// (>= 3.9 K u) is what covers the three f32 roundings of its epilogue, 3 u |2ab (s~ + eps_q)| <= 3.1 u (2ab).
+float mfma_f32_slack(uint32_t k_pad)
 {
-    return 0x1p-8f + 0x1p-21f + 0x1p-13f + (4.0f * (float)k_pad + 32.0f) * 0x1p-24f + 0x1p-20f;
+    return (6.0f * (float)k_pad + 64.0f) * 0x1p-24f + 0x1p-20f;
 }
 
 } // namespace vfsx
