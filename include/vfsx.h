@@ -250,6 +250,27 @@ int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint
                        int metric, vfsx_hit *d_hits, void *stream);
 
 /*
+ * The entry point that allocates nothing.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same results (every byte of every vfsx_hit) as vfsx_search_device, always through the exact
+ * scan (never the matrix-core batch path, whose workspaces grow on demand).  The device memory the scan needs
+ * beyond its inputs and outputs -- the per-workgroup top-k lists (8 MiB) and, when dim is not a whole number
+ * of 16-byte chunks or the metric is VFSX_EUCLIDEAN_I8DOMAIN, one launch's staged queries (1 MiB) -- is a
+ * static 9 MiB device array inside the library, one copy per GPU for the life of the process.  The call
+ * makes no hipMalloc / hipFree / allocating library call; the array's device address is looked up once per
+ * device (hipGetSymbolAddress) by vfsx_init, or by the first call on that device -- call vfsx_init first
+ * when even that must not happen on the hot path.  Limits, reported as VFSX_ERR_INVALID_VECTOR with a
+ * message naming the static workspace: k <= VFSX_MAX_K as everywhere; a staged query must fit 1 MiB
+ * (dim <= 262144 when staging applies); nq is unlimited (several launches share the workspace in stream
+ * order).  Every call on one GPU uses that GPU's array: calls on the same GPU that overlap (different
+ * streams without ordering, or different host threads) race on it.  Nothing in the array needs to start at
+ * zero: each launch overwrites what its select kernel reads.  Profiling (vfsx_corpus_set_profiling) does
+ * not time these calls.
+ */
+int vfsx_search_device_noalloc(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k,
+                               int metric, vfsx_hit *d_hits, void *stream);
+
+/*
  * Cross-shard merge (no reference counterpart): for each of nq
  * queries, d_in holds n_lists ranked lists of k hits laid out [list][query][k]
  * (the layout an all-gather of every rank's [query][k] block produces).  Writes

@@ -27,7 +27,7 @@ SYMBOLS = (
     "vfsx_corpus_destroy", "vfsx_corpus_append", "vfsx_corpus_append_quantize",
     "vfsx_corpus_rows", "vfsx_corpus_dim", "vfsx_corpus_dtype", "vfsx_corpus_set_row_base",
     "vfsx_corpus_get_rows_f32", "vfsx_corpus_get_rows_raw", "vfsx_corpus_get_ids",
-    "vfsx_corpus_fill_synthetic", "vfsx_search", "vfsx_search_device",
+    "vfsx_corpus_fill_synthetic", "vfsx_search", "vfsx_search_device", "vfsx_search_device_noalloc",
     "vfsx_merge_hits_device", "vfsx_merge_hits_host", "vfsx_corpus_set_profiling",
     "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats",
     "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_load_log_range", "vfsx_corpus_get_metadata_json",
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
     lib.vfsx_corpus_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.vfsx_search.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_int, u64p, f32p, u32p]
     lib.vfsx_search_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
+    lib.vfsx_search_device_noalloc.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
     lib.vfsx_merge_hits_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_int, vp]
     lib.vfsx_merge_hits_host.argtypes = [hitp, C.c_uint32, C.c_uint32, C.c_uint32, hitp]
     lib.vfsx_corpus_set_profiling.argtypes = [vp, C.c_int]

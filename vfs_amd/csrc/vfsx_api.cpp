@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -394,9 +395,20 @@ void prof_collect(vfsx_corpus *c)
     c->prof_used = 0;
 }
 
+// Device memory the exact scan needs beyond its inputs and outputs: the per-workgroup top-k lists the scan
+// kernel hands to the select kernel, and (only when the dimension is not a whole number of 16-byte chunks, or
+// for the integer-domain metric) a re-laid-out copy of the queries.  nullptr = the corpus' own buffers, grown
+// with hipMalloc on demand; vfsx_search_device_noalloc passes slices of the library's static device array.
+struct ScanWorkspace {
+    uint64_t *lists;
+    size_t lists_elems;
+    float *q_stage;
+    size_t q_stage_elems;
+};
+
 // the exact scan: enqueue the whole search on `s`; no host synchronisation
 void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
-                         vfsx_hit *d_hits, hipStream_t s)
+                         vfsx_hit *d_hits, hipStream_t s, const ScanWorkspace *ws = nullptr)
 {
     if (metric < VFSX_EUCLIDEAN || metric > VFSX_EUCLIDEAN_I8DOMAIN)
         fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
@@ -414,24 +426,36 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
     use_device(c);
     if (c->prof_used > 4096)
         prof_collect(c);
+    const bool profiling = c->profiling && !ws; // event creation allocates: never on the no-allocation path
 
+    // queries the kernels cannot read in place are staged: quantized and packed for the integer-domain
+    // metric, zero padded to a whole chunk otherwise
     const uint32_t q_stride_pad = c->d_chunks * c->epc;
-    const bool need_pad = (q_stride_pad != c->dim);
-    const float *q_ptr = d_queries;
-    uint32_t q_stride = c->dim;
-    if (i8dom) { // quantize the queries on the device; q_pad doubles as the packed-dword buffer
-        const uint32_t n_words = c->d_chunks * 4u;
-        q_stride = n_words + 4u;
+    const uint32_t n_words = c->d_chunks * 4u;
+    const bool staged = i8dom || q_stride_pad != c->dim;
+    const uint32_t q_stride = i8dom ? n_words + 4u : (staged ? q_stride_pad : c->dim);
+    float *q_stage = nullptr;
+    uint32_t stage_cap = nq; // queries the staging buffer holds
+    if (staged && ws) {
+        q_stage = ws->q_stage;
+        stage_cap = (uint32_t)std::min<uint64_t>(nq, ws->q_stage_elems / q_stride);
+        if (stage_cap == 0)
+            fail(VFSX_ERR_INVALID_VECTOR, "vfsx_search_device_noalloc: dim " + std::to_string(c->dim) +
+                                              " exceeds the static workspace (one staged query must fit " +
+                                              std::to_string(ws->q_stage_elems * sizeof(float)) + " bytes)");
+    } else if (staged) {
         c->q_pad.reserve((size_t)nq * q_stride);
-        HIP_CHECK(vfsx::launch_query_quantize(d_queries, nq, c->dim, c->scale, (uint32_t *)c->q_pad.p, n_words,
-                                              q_stride, s));
-        q_ptr = c->q_pad.p;
-    } else if (need_pad) {
-        c->q_pad.reserve((size_t)nq * q_stride_pad);
-        HIP_CHECK(vfsx::launch_query_pad(d_queries, nq, c->dim, c->q_pad.p, q_stride_pad, s));
-        q_ptr = c->q_pad.p;
-        q_stride = q_stride_pad;
+        q_stage = c->q_pad.p;
     }
+    auto stage_queries = [&](uint32_t q0, uint32_t qn) { // queries [q0, q0 + qn) -> q_stage[0 .. qn)
+        if (i8dom)
+            HIP_CHECK(vfsx::launch_query_quantize(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->scale,
+                                                  (uint32_t *)q_stage, n_words, q_stride, s));
+        else
+            HIP_CHECK(vfsx::launch_query_pad(d_queries + (size_t)q0 * c->dim, qn, c->dim, q_stage, q_stride, s));
+    };
+    if (staged && !ws)
+        stage_queries(0, nq);
 
     const uint32_t n_rowblocks = (uint32_t)((c->n_rows + 63u) / 64u);
     // a corpus that fits the 256 MiB Infinity Cache is re-read from it: keep the default
@@ -473,23 +497,33 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
         if (per_wave <= 16u && c->balanced_grid)
             grid_x = (n_rowblocks + 4u * per_wave - 1u) / (4u * per_wave);
     }
-    // queries per launch: bounded by gridDim.y and by a 256 MiB list workspace
-    uint32_t q_per_launch = nq;
+    // queries per launch: bounded by gridDim.y, by the list workspace (256 MiB of the corpus' own, or the
+    // caller's) and by the staging buffer
+    uint32_t q_per_launch = std::min<uint32_t>(nq, stage_cap);
+    uint64_t *lists = nullptr;
     if (grid_x) {
         const uint64_t per_q = (uint64_t)grid_x * k * sizeof(uint64_t);
-        q_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nq, (256ull << 20) / per_q));
+        const uint64_t lists_bytes = ws ? ws->lists_elems * sizeof(uint64_t) : (256ull << 20);
+        if (ws && per_q > lists_bytes)
+            fail(VFSX_ERR_INVALID_VECTOR, "vfsx_search_device_noalloc: " + std::to_string(grid_x) + " workgroup lists of k = " +
+                                              std::to_string(k) + " exceed the static workspace");
+        q_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_per_launch, lists_bytes / per_q));
         q_per_launch = std::min<uint32_t>(q_per_launch, 32768u);
-        c->lists.reserve((size_t)q_per_launch * grid_x * k);
+        if (!ws)
+            c->lists.reserve((size_t)q_per_launch * grid_x * k);
+        lists = ws ? ws->lists : c->lists.p;
     }
     for (uint32_t q0 = 0; q0 < nq; q0 += q_per_launch) {
         const uint32_t qn = std::min(q_per_launch, nq - q0);
+        if (staged && ws)
+            stage_queries(q0, qn); // the previous launch's kernels are ahead of it on the stream
         if (grid_x) {
             ScanArgs a{};
             a.corpus = c->d_corpus;
             a.row_norms = c->d_norms;
-            a.queries = q_ptr + (size_t)q0 * q_stride;
+            a.queries = !staged ? d_queries + (size_t)q0 * c->dim : (ws ? q_stage : q_stage + (size_t)q0 * q_stride);
             a.lut = c->d_lut;
-            a.lists = c->lists.p;
+            a.lists = lists;
             a.n_rows = (uint32_t)c->n_rows;
             a.d_chunks = c->d_chunks;
             a.n_rowblocks = n_rowblocks;
@@ -497,17 +531,19 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
             a.k = k;
             a.n_lists = grid_x;
             size_t slot = 0;
-            prof_begin(c, s, slot);
+            if (profiling)
+                prof_begin(c, s, slot);
             if (i8dom)
                 HIP_CHECK(vfsx::launch_scan_i8dom(a, qn, grid_x, nt != 0, c->scale, s));
             else if (wide)
                 HIP_CHECK(vfsx::launch_scan_i8_wide(metric, a, qn, grid_x, nt != 0, c->unroll_override, s));
             else
                 HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
-            prof_end(c, s, slot);
+            if (profiling)
+                prof_end(c, s, slot);
         }
         SelectArgs sa{};
-        sa.lists = c->lists.p;
+        sa.lists = lists;
         sa.ids = c->explicit_ids ? c->d_ids : nullptr;
         sa.out = d_hits + (size_t)q0 * k;
         sa.row_base = c->row_base;
@@ -728,6 +764,37 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     exact_search_device(c, d_queries, nq, k, metric, d_hits, s);
 }
 
+// ---- the entry point that allocates nothing (vfsx_search_device_noalloc) ----------------------------------
+// Its workspace is this file-scope device array instead of hipMalloc'ed buffers: every GPU the library runs on
+// holds one copy (9 MiB) until the process ends.  In host code the NAME `scratch` is only a stand-in for the
+// symbol: it is never passed to a kernel or a HIP call.  Its device address is looked up once per device
+// with hipGetSymbolAddress (that device current) and kept in g_scratch_ptr[device]; kernels and memsets get
+// that pointer.
+constexpr size_t kScratchListsBytes = 8u << 20; // per-workgroup top-k lists: <= 1024 lists x k <= 1024 x 8 B
+constexpr size_t kScratchQueryBytes = 1u << 20; // staged (padded / quantized) queries of one launch
+static __device__ __align__(256) unsigned char scratch[kScratchListsBytes + kScratchQueryBytes];
+
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxScratchDevices] = {};
+
+// device address of this device's copy of `scratch` (looked up on first use; vfsx_init does it up front)
+void *scratch_for_device(int device)
+{
+    if (device < 0 || device >= kMaxScratchDevices)
+        fail(VFSX_ERR_NO_DEVICE, "HIP device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        HIP_CHECK(hipSetDevice(device));
+        void *p = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p)
+            fail(VFSX_ERR_INTERNAL, "hipGetSymbolAddress returned a null address for the static workspace");
+        g_scratch_ptr[device] = p;
+    }
+    return g_scratch_ptr[device];
+}
+
 vfsx_corpus *checked(vfsx_corpus *c)
 {
     if (!c)
@@ -776,6 +843,7 @@ int vfsx_init(int n_devices)
             if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("VFSX_ALLOW_ANY_ARCH"))
                 fail(VFSX_ERR_NO_DEVICE, std::string("vfsx is built for gfx950 only, device ") + std::to_string(d) +
                                              " is " + prop.gcnArchName);
+            (void)scratch_for_device(d); // vfsx_search_device_noalloc then does no set-up work on its first call
         }
     });
 }
@@ -1009,6 +1077,22 @@ int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint
                        vfsx_hit *d_hits, void *stream)
 {
     return guarded([&] { search_device_impl(checked(c), d_queries, nq, k, metric, d_hits, (hipStream_t)stream); });
+}
+
+int vfsx_search_device_noalloc(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                               vfsx_hit *d_hits, void *stream)
+{
+    return guarded([&] {
+        checked(c);
+        ScanWorkspace ws{};
+        unsigned char *base = (unsigned char *)scratch_for_device(c->device);
+        ws.lists = (uint64_t *)base;
+        ws.lists_elems = kScratchListsBytes / sizeof(uint64_t);
+        ws.q_stage = (float *)(base + kScratchListsBytes);
+        ws.q_stage_elems = kScratchQueryBytes / sizeof(float);
+        // always the exact scan: the matrix-core batch path grows its workspaces with hipMalloc
+        exact_search_device(c, d_queries, nq, k, metric, d_hits, (hipStream_t)stream, &ws);
+    });
 }
 
 int vfsx_merge_hits_device(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k, vfsx_hit *d_out,

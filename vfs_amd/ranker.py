@@ -194,6 +194,13 @@ class Corpus:
         _lib.check(self._lib.vfsx_search_device(self._h, C.c_void_p(d_queries_ptr), nq, k, int(metric),
                                                 C.c_void_p(d_hits_ptr), C.c_void_p(stream_ptr)))
 
+    def search_device_noalloc(self, d_queries_ptr: int, nq: int, k: int, metric: int, d_hits_ptr: int,
+                              stream_ptr: int = 0) -> None:
+        """search_device for callers that cannot allocate (HIP graph capture, tight serving loops): the same
+        exact scan on the library's static device workspace; no hipMalloc / hipFree on this call."""
+        _lib.check(self._lib.vfsx_search_device_noalloc(self._h, C.c_void_p(d_queries_ptr), nq, k, int(metric),
+                                                        C.c_void_p(d_hits_ptr), C.c_void_p(stream_ptr)))
+
     def enable_mfma(self, enabled: bool = True) -> None:
         """Build (or drop) the bf16 mirror that lets large Cosine batches run on the matrix cores."""
         _lib.check(self._lib.vfsx_corpus_enable_mfma(self._h, 1 if enabled else 0))
