@@ -283,6 +283,51 @@ int vfsx_merge_hits_device(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, 
 int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint32_t k,
                          vfsx_hit *out);
 
+/* ---- row-sharded search over several GPUs (no reference counterpart) ------------------
+ *
+ * One process per GPU.  Rank g holds a contiguous range of the scan order (vfsx_corpus_set_row_base) and
+ * scans it locally; the per-rank top-k lists are exchanged with ONE RCCL all-gather per query batch
+ * (ncclAllGather over xGMI, nq * k * 24 bytes per rank) and merged on every rank by (distance, global row),
+ * which is the reference's (distance, first-seen) order (rank.rs:170) because the ranges are contiguous.
+ * RCCL (librccl.so.1) is loaded at run time on the first vfsx_comm_* call; without it these entry points
+ * fail with VFSX_ERR_NO_DEVICE and everything else keeps working.
+ *
+ * Bootstrap, as with any NCCL/RCCL communicator: rank 0 calls vfsx_comm_unique_id and hands the 128 bytes to
+ * every rank by whatever transport the host already has (a file, a socket, MPI, torch.distributed); then all
+ * ranks call vfsx_comm_init (collective: it returns once every rank has joined).
+ */
+#define VFSX_COMM_ID_BYTES 128
+typedef struct vfsx_comm vfsx_comm;
+
+int vfsx_comm_unique_id(void *id_out /* VFSX_COMM_ID_BYTES */);
+/* `device`: the HIP device this rank's corpus lives on.  NULL on failure (vfsx_last_error). */
+vfsx_comm *vfsx_comm_init(int rank, int world, const void *id, int device);
+void vfsx_comm_destroy(vfsx_comm *comm);
+int vfsx_comm_rank(const vfsx_comm *comm);
+int vfsx_comm_world(const vfsx_comm *comm);
+/* RCCL's version code (e.g. 22703), 0 when RCCL cannot be loaded. */
+int vfsx_comm_rccl_version(void);
+
+/*
+ * The collective search: vfsx_search_device on this rank's shard, the all-gather, the merge -- all enqueued
+ * on `stream` (the matrix-core batch path, if enabled on the corpus, synchronises it once as documented
+ * below).  Every rank must call it with the same nq / k; d_hits[nq*k] receives the same global ranking on
+ * every rank.
+ */
+int vfsx_search_sharded(vfsx_corpus *c, vfsx_comm *comm, const float *d_queries, uint32_t nq, uint32_t k,
+                        int metric, vfsx_hit *d_hits, void *stream);
+
+/* The same with host buffers, shaped like vfsx_search (what a Ranker-level caller uses): queries[nq*dim] in,
+ * out_ids / out_dist [nq*k] and out_count[nq] out; runs on a stream the communicator owns and returns when the
+ * results are on the host. */
+int vfsx_search_sharded_host(vfsx_corpus *c, vfsx_comm *comm, const float *queries, uint32_t nq, uint32_t k,
+                             int metric, uint64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+/* The exchange alone, for hosts that produce the local lists themselves (e.g. one scan launch per query):
+ * d_local[nq*k] = this rank's ranked lists; all-gather + merge into d_hits[nq*k]. */
+int vfsx_comm_merge_hits(vfsx_comm *comm, const vfsx_hit *d_local, uint32_t nq, uint32_t k, vfsx_hit *d_hits,
+                         void *stream);
+
 /*
  * Many-query batches on the matrix cores (no reference counterpart: the reference has no
  * multi-query API, rank.rs:90; a batch is defined as the single-query result per query).

@@ -34,6 +34,11 @@ ids_l, dist_l, cnt_l = sharded.hits_to_arrays(local)
 assert (ids_m == ids_l).all() and (dist_m.view(np.uint32) == dist_l.view(np.uint32)).all() and (cnt_m == k).all()
 ids_e, dist_e, _ = sc.local.search_batch(q, k, 1)
 assert (ids_m == ids_e).all()
+# ShardedCorpus under the nccl backend exchanges through the library's own communicator (vfsx_comm_*),
+# bootstrapped over this process group
+assert sc.comm is not None and sc.comm.world == 1
+ids_c, dist_c, cnt_c = sharded.hits_to_arrays(sc.search(dq, k, 1))
+assert (ids_c == ids_e).all() and (dist_c.view(np.uint32) == dist_e.view(np.uint32)).all()
 sc.close()
 dist.destroy_process_group()
-print("OK rccl all_gather_into_tensor + vfsx_merge_hits_device")
+print("OK rccl all_gather_into_tensor + vfsx_merge_hits_device + vfsx_search_sharded")

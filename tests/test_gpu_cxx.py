@@ -24,3 +24,13 @@ def test_cxx_ranker_parity_against_oracle():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert r.stdout.strip().splitlines()[-1].startswith("ok ")
+
+
+def test_cxx_sharded_search_end_to_end():
+    """tests/cxx/sharded_parity.cpp: SURVEY 8(e) from a C++ host -- two shards on one GPU merged on the device, and
+    the world-1 RCCL communicator (vfsx_comm_*, vfsx_search_sharded[_host], vfsx_comm_merge_hits) -- vs the oracle."""
+    exe = os.path.join(ROOT, "tests", "cxx", "sharded_parity")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.strip().splitlines()[-1].startswith("ok ")

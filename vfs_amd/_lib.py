@@ -31,7 +31,10 @@ SYMBOLS = (
     "vfsx_merge_hits_device", "vfsx_merge_hits_host", "vfsx_corpus_set_profiling",
     "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats",
     "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_load_log_range", "vfsx_corpus_get_metadata_json",
+    "vfsx_comm_unique_id", "vfsx_comm_init", "vfsx_comm_destroy", "vfsx_comm_rank", "vfsx_comm_world",
+    "vfsx_comm_rccl_version", "vfsx_search_sharded", "vfsx_search_sharded_host", "vfsx_comm_merge_hits",
 )
+COMM_ID_BYTES = 128
 
 
 class Hit(C.Structure):
@@ -114,6 +117,16 @@ def load() -> C.CDLL:
     lib.vfsx_corpus_enable_mfma.argtypes = [vp, C.c_int]
     lib.vfsx_corpus_mfma_stats.argtypes = [vp, u64p, u64p, C.c_int]
     lib.vfsx_corpus_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
+    lib.vfsx_comm_unique_id.argtypes = [vp]
+    lib.vfsx_comm_init.restype = vp
+    lib.vfsx_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int]
+    lib.vfsx_comm_destroy.restype = None
+    lib.vfsx_comm_destroy.argtypes = [vp]
+    lib.vfsx_comm_rank.argtypes = [vp]
+    lib.vfsx_comm_world.argtypes = [vp]
+    lib.vfsx_search_sharded.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
+    lib.vfsx_comm_merge_hits.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+    lib.vfsx_search_sharded_host.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_int, u64p, f32p, u32p]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
     _lib = lib

@@ -111,6 +111,10 @@ struct DeviceBuf {
 
 } // namespace
 
+namespace vfsx {
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+} // namespace vfsx
+
 struct vfsx_corpus {
     int device = 0;
     uint32_t dim = 0;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "vfsx.h"
 
 namespace vfsx {
@@ -137,6 +139,10 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
                               const int *only_flagged, hipStream_t s);
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);
+
+// thread-local message behind vfsx_last_error() (vfsx_api.cpp), for the other host translation units
+void set_last_error(const char *msg);
+inline void set_last_error(const std::string &msg) { set_last_error(msg.c_str()); }
 
 // host helpers shared with the host merge
 inline uint32_t host_dist_key(float d)

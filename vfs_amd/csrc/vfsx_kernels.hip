@@ -590,8 +590,82 @@ __global__ void get_rows_kernel(const uint4 *__restrict__ corpus, uint32_t dim, 
 }
 
 // ---- cross-shard merge of ranked hit lists ------------------------------------------------------
-// in: [n_lists][nq][k]; one workgroup per query; rank-by-counting under the strict
-// total order (key(dist), row, input index).
+// in: [n_lists][nq][k], every list already ranked (ascending by (distance key, row), invalid entries last:
+// what select / rescore / this kernel write).  Strict total order: (valid first, key(dist), row, list).
+
+// n_lists <= 64: a G-way merge in one wave per query.  Lane l holds the head of list l; k times the wave
+// takes the smallest head (a 6-step butterfly over the 3-word order tuple) and that lane advances: O(k log 64)
+// wave steps instead of the (n_lists k)^2 comparisons of rank-by-counting below.
+struct MergeHead {
+    uint64_t a; // (invalid << 32) | key(dist): valid entries first, then by distance
+    uint64_t row;
+    uint32_t list;
+};
+__device__ __forceinline__ bool head_less(const MergeHead &x, const MergeHead &y)
+{
+    if (x.a != y.a)
+        return x.a < y.a;
+    if (x.row != y.row)
+        return x.row < y.row;
+    return x.list < y.list;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void merge_hits_wave_kernel(const vfsx_hit *__restrict__ in, uint32_t n_lists,
+                                                            uint32_t nq, uint32_t k, vfsx_hit *__restrict__ out)
+{
+    const uint32_t qi = blockIdx.x, lane = threadIdx.x;
+    const vfsx_hit *mine = in + ((size_t)(lane < n_lists ? lane : 0u) * nq + qi) * k;
+    uint32_t pos = lane < n_lists ? 0u : k; // exhausted lists (and idle lanes) sort after everything
+    vfsx_hit h{};
+    auto load_head = [&]() -> MergeHead {
+        MergeHead m;
+        m.list = lane;
+        if (pos < k) {
+            h = mine[pos];
+            m.a = ((uint64_t)((h.flags & 1u) ^ 1u) << 32) | dist_key(h.dist);
+            m.row = h.row;
+        } else {
+            m.a = ~0ull;
+            m.row = ~0ull;
+        }
+        return m;
+    };
+    MergeHead head = load_head();
+    for (uint32_t j = 0; j < k; ++j) {
+        MergeHead best = head;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            MergeHead o;
+            o.a = shfl_xor_u64(best.a, m);
+            o.row = shfl_xor_u64(best.row, m);
+            o.list = (uint32_t)__shfl_xor((int)best.list, m, 64);
+            if (head_less(o, best))
+                best = o;
+        }
+        if (best.list == lane) { // exactly one lane: the tuple ends in the (unique) list index
+            if (pos < k) {
+                out[(size_t)qi * k + j] = h;
+            } else { // every list is exhausted: fewer than k entries in all (cannot happen for k lists of k)
+                vfsx_hit e;
+                e.dist = __uint_as_float(0x7fc00000u);
+                e.flags = 0;
+                e.row = ~0ull;
+                e.id = ~0ull;
+                out[(size_t)qi * k + j] = e;
+            }
+            ++pos;
+            head = load_head();
+        }
+    }
+}
+
+// any n_lists: rank-by-counting, one workgroup per query (only used beyond 64 lists)
 __global__ __launch_bounds__(kBlock) void merge_hits_kernel(const vfsx_hit *__restrict__ in,
                                                             uint32_t n_lists, uint32_t nq, uint32_t k,
                                                             vfsx_hit *__restrict__ out)
@@ -865,7 +939,10 @@ hipError_t launch_move_records(const void *src, void *dst, const uint32_t *d_idx
 hipError_t launch_merge_hits(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, uint32_t k,
                              vfsx_hit *d_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(merge_hits_kernel, dim3(nq), dim3(kBlock), 0, s, d_in, n_lists, nq, k, d_out);
+    if (n_lists <= 64u)
+        hipLaunchKernelGGL(merge_hits_wave_kernel, dim3(nq), dim3(64), 0, s, d_in, n_lists, nq, k, d_out);
+    else
+        hipLaunchKernelGGL(merge_hits_kernel, dim3(nq), dim3(kBlock), 0, s, d_in, n_lists, nq, k, d_out);
     return hipGetLastError();
 }
 

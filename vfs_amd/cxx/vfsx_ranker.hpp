@@ -4,6 +4,7 @@
 // device-resident vfsx::Corpus standing where VFSManager did on this path.
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
@@ -73,6 +74,8 @@ public:
         check(vfsx_corpus_load_log(h_, path.c_str(), &n));
         return n;
     }
+    // this shard's first global scan position (row-sharded stores)
+    void set_row_base(uint64_t row_base) { check(vfsx_corpus_set_row_base(h_, row_base)); }
     // many-query batches on the matrix cores (no reference counterpart; results unchanged)
     void enable_mfma(bool on = true) { check(vfsx_corpus_enable_mfma(h_, on ? 1 : 0)); }
 
@@ -96,6 +99,34 @@ private:
     vfsx_corpus *h_ = nullptr;
     uint32_t dim_;
     bool quantize_;
+};
+
+// One rank's handle on the RCCL communicator of a row-sharded store (include/vfsx.h, vfsx_comm_*; no
+// reference counterpart).  Rank 0 makes the id, the host hands it to every rank, all ranks construct.
+class Comm {
+public:
+    using Id = std::array<char, VFSX_COMM_ID_BYTES>;
+    static Id unique_id()
+    {
+        Id id{};
+        check(vfsx_comm_unique_id(id.data()));
+        return id;
+    }
+    Comm(int rank, int world, const Id &id, int device = 0)
+    {
+        h_ = vfsx_comm_init(rank, world, id.data(), device);
+        if (!h_)
+            throw Error(VFSX_ERR_INTERNAL, vfsx_last_error());
+    }
+    ~Comm() { vfsx_comm_destroy(h_); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    int rank() const { return vfsx_comm_rank(h_); }
+    int world() const { return vfsx_comm_world(h_); }
+    vfsx_comm *handle() const { return h_; }
+
+private:
+    vfsx_comm *h_ = nullptr;
 };
 
 class Ranker {
@@ -125,6 +156,35 @@ public:
         check(vfsx_search(manager.handle(), query.data(), 1, (uint32_t)limit, (int)distance_method_, ids.data(),
                           dist.data(), &count));
         std::vector<std::pair<uint64_t, float>> out;
+        out.reserve(count);
+        for (uint32_t i = 0; i < count; ++i)
+            out.emplace_back(ids[i], dist[i]);
+        return out;
+    }
+
+    // The same search over a row-sharded store: `shard` is this rank's contiguous range of the scan order
+    // (Corpus::set_row_base), every rank calls with the same query and gets the same global ranking
+    // (local scan -> ncclAllGather -> merge by (distance, global row)).
+    std::vector<std::pair<uint64_t, float>> search_sharded(const std::vector<float> &query, size_t num_vectors_per_iteration,
+                                                           std::optional<size_t> result_limit, Corpus &shard,
+                                                           Comm &comm) const
+    {
+        if (search_type_ != SearchType::Exact)
+            throw Error(VFSX_ERR_INTERNAL, "approximate (HNSW) search is outside the vfsx hot path");
+        if (query.size() != shard.dim())
+            throw Error(VFSX_ERR_INVALID_VECTOR, "Los vectores deben tener la misma dimensión");
+        const size_t limit = result_limit.value_or(5);
+        if (limit == 0)
+            throw Error(VFSX_ERR_INVALID_VECTOR, "result_limit must be >= 1");
+        // num_vectors_per_iteration == 0 (empty result) must still join the collective: every rank calls
+        std::vector<uint64_t> ids(limit);
+        std::vector<float> dist(limit);
+        uint32_t count = 0;
+        check(vfsx_search_sharded_host(shard.handle(), comm.handle(), query.data(), 1, (uint32_t)limit,
+                                       (int)distance_method_, ids.data(), dist.data(), &count));
+        std::vector<std::pair<uint64_t, float>> out;
+        if (num_vectors_per_iteration == 0)
+            return out;
         out.reserve(count);
         for (uint32_t i = 0; i < count; ++i)
             out.emplace_back(ids[i], dist[i]);

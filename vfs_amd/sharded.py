@@ -41,14 +41,89 @@ def merge_hits_host(gathered: np.ndarray, k: int) -> np.ndarray:
     return out
 
 
+class Comm:
+    """vfsx_comm (include/vfsx.h): the library's own RCCL communicator -- ncclAllGather + device merge behind
+    the C ABI, the path a C / C++ / Rust host takes.  `Comm.bootstrap()` distributes rank 0's 128-byte id over
+    an existing torch.distributed group (any backend); `Comm(rank, world, id, device)` takes an id obtained
+    any other way."""
+
+    def __init__(self, rank: int, world: int, uid: bytes, device: int):
+        self._lib = _lib.load()
+        assert len(uid) == _lib.COMM_ID_BYTES
+        buf = C.create_string_buffer(uid, _lib.COMM_ID_BYTES)
+        self._h = self._lib.vfsx_comm_init(int(rank), int(world), buf, int(device))
+        if not self._h:
+            raise _lib.VfsxError(_lib.ERR_INTERNAL, self._lib.vfsx_last_error().decode("utf-8", "replace"))
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(lib.vfsx_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def bootstrap(cls, device: int, group=None) -> "Comm":
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0], device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def merge_hits(self, d_local_ptr: int, nq: int, k: int, d_out_ptr: int, stream_ptr: int = 0) -> None:
+        _lib.check(self._lib.vfsx_comm_merge_hits(self._h, C.c_void_p(d_local_ptr), nq, k, C.c_void_p(d_out_ptr),
+                                                  C.c_void_p(stream_ptr)))
+
+    def search(self, corpus, d_queries_ptr: int, nq: int, k: int, metric: int, d_hits_ptr: int,
+               stream_ptr: int = 0) -> None:
+        _lib.check(self._lib.vfsx_search_sharded(corpus.handle, self._h, C.c_void_p(d_queries_ptr), nq, k, int(metric),
+                                                 C.c_void_p(d_hits_ptr), C.c_void_p(stream_ptr)))
+
+    def search_host(self, corpus, queries, k: int, metric: int):
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, corpus.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), dtype=np.uint64)
+        dist = np.full((nq, k), np.nan, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        _lib.check(self._lib.vfsx_search_sharded_host(
+            corpus.handle, self._h, q.ctypes.data_as(C.POINTER(C.c_float)), nq, k, int(metric),
+            ids.ctypes.data_as(C.POINTER(C.c_uint64)), dist.ctypes.data_as(C.POINTER(C.c_float)),
+            cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return ids, dist, cnt
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.vfsx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def exchange_and_merge(local_hits, k: int, group=None, device_index: Optional[int] = None,
-                       force_collective: bool = False):
+                       force_collective: bool = False, comm: Optional[Comm] = None):
     """local_hits: torch int32 tensor [nq, k, 6] (a view of vfsx_hit[nq*k]) on this
-    rank's device (cuda -> RCCL all-gather + device merge; cpu -> gloo + host merge).
+    rank's device.  With `comm` (the library's RCCL communicator): vfsx_comm_merge_hits, i.e. ncclAllGather +
+    device merge inside libvfsx.so.  Otherwise through torch.distributed: cuda + nccl backend -> RCCL
+    all-gather + device merge; anything else (gloo: CPU tests, rehearsals) -> host tensors + host merge.
     Returns the merged [nq, k, 6] tensor (same device), identical on every rank."""
     import torch
     import torch.distributed as dist
 
+    if comm is not None:
+        out = torch.empty_like(local_hits)
+        src = local_hits.contiguous()
+        stream = torch.cuda.current_stream(local_hits.device).cuda_stream
+        comm.merge_hits(src.data_ptr(), src.shape[0], k, out.data_ptr(), stream)
+        return out
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     nq = local_hits.shape[0]
     if world == 1 and not (force_collective and dist.is_initialized()):
@@ -88,11 +163,19 @@ class ShardedCorpus:
     """This rank's shard of a row-sharded corpus + the collective search."""
 
     def __init__(self, dim: int, quantize: bool = False, scale: float = 127.0, capacity_rows: int = 0,
-                 device: int = 0, group=None):
+                 device: int = 0, group=None, use_vfsx_comm: Optional[bool] = None):
+        """use_vfsx_comm: exchange through the library's own RCCL communicator (the C-ABI path).  Default:
+        yes when the process group's backend is nccl (= RCCL), no otherwise (gloo rehearsals on CPU)."""
+        import torch.distributed as dist
         from .ranker import Corpus
         self.local = Corpus(dim, quantize=quantize, scale=scale, capacity_rows=capacity_rows, device=device)
         self.device = device
         self.group = group
+        self.comm = None
+        if use_vfsx_comm is None:
+            use_vfsx_comm = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if use_vfsx_comm:
+            self.comm = Comm.bootstrap(device, group)
 
     def set_row_base(self, row_base: int) -> None:
         self.local.set_row_base(row_base)
@@ -116,8 +199,13 @@ class ShardedCorpus:
         nq = d_queries.shape[0]
         local = torch.empty((nq, k, HIT_WORDS), dtype=torch.int32, device=d_queries.device)
         stream = torch.cuda.current_stream(d_queries.device).cuda_stream
+        if self.comm is not None:  # local scan + ncclAllGather + merge, all inside libvfsx.so
+            self.comm.search(self.local, d_queries.data_ptr(), nq, k, int(metric), local.data_ptr(), stream)
+            return local
         self.local.search_device(d_queries.data_ptr(), nq, k, int(metric), local.data_ptr(), stream)
         return exchange_and_merge(local, k, group=self.group, device_index=self.device)
 
     def close(self) -> None:
+        if self.comm is not None:
+            self.comm.close()
         self.local.close()
