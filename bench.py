@@ -5,13 +5,17 @@ Contract (see the task's bench rules): `python bench.py --gpus N --steps K --war
   * N = 1: workload C2 = BASELINE.json configs[1]: 1M x 768 f32 Cosine, exact top-10,
     single-query scans.  A step = `--queries-per-step` distinct queries, each scanned
     by its own kernel launch (the corpus is re-read from HBM for every query).
-  * N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every
-    rank holds its own 1M x 768 shard of a row-sharded N*1M-row corpus; every query is
-    scanned on every shard, the per-shard top-10 lists of a step are exchanged with ONE
-    RCCL all-gather and merged on the device by (distance, global row).
-    `value` = shard scans per second = N x (queries/s answered against the whole
-    corpus): the units all ranks processed / max-over-ranks time.  `qps_global` is the
-    plain queries/s against the N*1M-row corpus.
+  * N > 1: workload C5 = BASELINE.json configs[4] cut to N ranks: every rank holds a
+    12.5M x 768 f32 shard (38.4 GB) of a row-sharded N*12.5M-row corpus -- at N = 8 the
+    100M x 768 Euclidean configuration.  Every query is scanned on every shard, the per-shard
+    top-10 lists of a step are exchanged with ONE RCCL all-gather (the library's own
+    communicator, vfsx_comm_*: ncclAllGather + device merge by (distance, global row)).
+    `value` = queries per second answered against the WHOLE corpus.  Weak scaling: the corpus
+    grows with N, so ideal scaling is a constant `value` (and N x the aggregate HBM rate, which
+    `roofline` reports against N x 8 TB/s).  `--workload c2` selects 1M-row shards instead.
+    Started from a plain shell (`python bench.py --gpus N`, WORLD_SIZE unset) the script
+    launches its own N ranks through torch.distributed.run and relays rank 0's JSON line; under
+    torch.distributed.run it is one of the ranks.
 Inputs are resident in HBM before the timed region (synthetic, generated on device).
 """
 from __future__ import annotations
@@ -19,40 +23,46 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-
-WORKLOADS = {
-    # name: (rows per GPU, dim, quantize, metric, label)
-    "c2": (1_000_000, 768, False, 1, "C2 1Mx768 f32 Cosine exact top-10, single-query scan"),
-    "c2e": (1_000_000, 768, False, 0, "1Mx768 f32 Euclidean exact top-10, single-query scan"),
-    "c3": (10_000_000, 128, True, 0, "C3 10Mx128 int8 QuantizedVector Euclidean exact top-10"),
-    "c3i": (10_000_000, 128, True, 4, "10Mx128 int8, LABELLED integer-domain fast mode (extension, not the reference's "
-                                       "arithmetic; SURVEY 8a A6(ii)), exact top-10"),
-    "c1": (100_000, 128, False, 2, "C1 100kx128 f32 SimdEuclidean exact top-10"),
-    "c5": (12_500_000, 768, False, 0, "C5 shard 12.5Mx768 f32 Euclidean (100Mx768 over 8 GPUs)"),
-    "c4e": (10_000_000, 1024, False, 0, "4096-query batch x 10Mx1024 Euclidean as Q.X^T on bf16 MFMA + per-row upper-bound "
-                                         "epilogue + fused top-k, exact f32 re-score (extension of C4 to the Euclidean metric)"),
-    "c4": (10_000_000, 1024, False, 1, "C4 4096-query batch x 10Mx1024 Cosine as Q.X^T on bf16 MFMA + fused top-k, "
-                                        "exact f32 re-score"),
-}
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
+WORKLOADS = {
+    # name: (rows per GPU, dim, quantize, metric, queries per step, label)
+    "c2": (1_000_000, 768, False, 1, 256, "C2 1Mx768 f32 Cosine exact top-10, single-query scan"),
+    "c2e": (1_000_000, 768, False, 0, 256, "1Mx768 f32 Euclidean exact top-10, single-query scan"),
+    "c3": (10_000_000, 128, True, 0, 512, "C3 10Mx128 int8 QuantizedVector Euclidean exact top-10"),
+    "c3i": (10_000_000, 128, True, 4, 512, "10Mx128 int8, LABELLED integer-domain fast mode (extension, not the "
+                                            "reference's arithmetic; SURVEY 8a A6(ii)), exact top-10"),
+    "c1": (100_000, 128, False, 2, 4096, "C1 100kx128 f32 SimdEuclidean exact top-10"),
+    "c1d64": (100_000, 64, False, 2, 4096, "100kx64 f32 SimdEuclidean exact top-10 (the widest dimension the reference's "
+                                           "own Simd path accepts, rank.rs:303)"),
+    "c5": (12_500_000, 768, False, 0, 32, "C5 shard 12.5Mx768 f32 Euclidean per GPU (100Mx768 over 8 GPUs), "
+                                          "single-query scan, RCCL all-gather top-k merge"),
+    "c4e": (10_000_000, 1024, False, 0, 4096, "4096-query batch x 10Mx1024 Euclidean as Q.X^T on bf16 MFMA + per-row "
+                                              "upper-bound epilogue + fused top-k, exact f32 re-score (extension of C4 to "
+                                              "the Euclidean metric)"),
+    "c4": (10_000_000, 1024, False, 1, 4096, "C4 4096-query batch x 10Mx1024 Cosine as Q.X^T on bf16 MFMA + fused top-k, "
+                                             "exact f32 re-score"),
+}
+METRIC_NAMES = ["euclidean", "cosine", "simd_euclidean", "simd_cosine", "euclidean_i8_domain"]
 
-def main() -> int:
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--queries-per-step", type=int, default=16)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU, c5 (12.5M-row shard per rank) on several")
+    ap.add_argument("--queries-per-step", type=int, default=0, help="default: per workload, ~0.1 s of device time")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mode", default="single", choices=["single", "batch"],
                     help="single: one scan launch per query (the headline); batch: one call per step, "
@@ -62,35 +72,104 @@ def main() -> int:
     ap.add_argument("--metric", type=int, default=-1, help="override the metric 0..3 (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
-    ap.add_argument("--cpu-sample-queries", type=int, default=48)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: stop after about this long")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="join the ranks, exchange one collective, print the configuration; touches no GPU "
+                         "(launcher rehearsal on CPU with VFSX_BENCH_BACKEND=gloo)")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
 
-    import vfs_amd
-    from vfs_amd import sharded, synth
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as children of this process (which has
+    touched no GPU and does not import torch) and relay their output -- rank 0 prints the JSON line -- and exit
+    code.  The driver's own form (torch.distributed.run ... bench.py) lands in main() directly."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
-                  f"(one rank per GPU)", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    workload = args.workload or ("c2" if world == 1 else "c5")
+    rows, dim, quantize, metric, qps_default, label = WORKLOADS[workload]
+    mfma = workload in ("c4", "c4e")
+    if mfma:
+        args.mode = "batch"
+        if args.steps == 40:
+            args.steps, args.warmup = 5, 1
+    if args.rows:
+        rows = args.rows
+    if args.dim:
+        dim, label = args.dim, label + f" [dim overridden to {args.dim}]"
+    if args.metric >= 0:
+        metric, label = args.metric, label + f" [metric overridden to {args.metric}]"
+    k = args.k
+    qps_step = args.queries_per_step or qps_default
+    elem = 1 if quantize else 4
+    config = {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k,
+              "storage": "i8 (QuantizedVector, dequantized on read)" if quantize else "f32",
+              "queries_per_step": qps_step, "mode": args.mode, "metric_fn": METRIC_NAMES[metric],
+              "sharding": f"row-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"}
+
+    import torch
+    import torch.distributed as dist
+
+    backend = os.environ.get("VFSX_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo for rehearsals
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    if args.dry_run:
+        joined = 1
+        if world > 1:
+            use_nccl = backend == "nccl" and torch.cuda.is_available()
+            dist.init_process_group("nccl" if use_nccl else "gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            if use_nccl:
+                t = t.cuda(local_rank % torch.cuda.device_count())
+            dist.all_reduce(t)
+            joined = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "ranks_joined": joined, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "config": config}), flush=True)
+        return 0
+
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (vfs_amd has no CPU path)", file=sys.stderr)
         return 2
+    import vfs_amd
+    from vfs_amd import sharded, synth
+
     # one rank per GPU; the modulo only matters when rehearsing N ranks on fewer GPUs
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("VFSX_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            comm = sharded.Comm.bootstrap(local_rank)  # the library's own RCCL communicator (vfsx_comm_*)
         else:
             dist.init_process_group(backend)
 
@@ -101,24 +180,6 @@ def main() -> int:
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     dbg("process group up")
-    rows, dim, quantize, metric, label = WORKLOADS[args.workload]
-    mfma = args.workload in ("c4", "c4e")
-    if mfma:
-        args.mode = "batch"
-        if args.queries_per_step == 16:
-            args.queries_per_step = 4096
-        if args.steps == 40:
-            args.steps, args.warmup = 5, 1
-    if args.rows:
-        rows = args.rows
-    if args.dim:
-        dim, label = args.dim, label + f" [dim overridden to {args.dim}]"
-    if args.metric >= 0:
-        metric, label = args.metric, label + f" [metric overridden to {args.metric}]"
-    k = args.k
-    qps_step = args.queries_per_step
-    elem = 1 if quantize else 4
-
     corpus = vfs_amd.Corpus(dim, quantize=quantize, capacity_rows=rows, device=local_rank)
     corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
     corpus.set_row_base(rank * rows)
@@ -131,6 +192,7 @@ def main() -> int:
     d_q = torch.from_numpy(q_host).to(dev)
     hit_words = 6  # vfsx_hit = 24 bytes = 6 x u32
     d_local = torch.zeros((qps_step, k, hit_words), dtype=torch.int32, device=dev)
+    d_global = torch.zeros((qps_step, k, hit_words), dtype=torch.int32, device=dev)
 
     def run_step(step_idx: int) -> None:
         stream = torch.cuda.current_stream().cuda_stream
@@ -140,7 +202,9 @@ def main() -> int:
         else:
             for j in range(qps_step):  # one scan launch per query: "single-query scan"
                 corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
-        if world > 1:  # ONE all-gather per step (queries_per_step x k x 24 B per rank), device merge
+        if comm is not None:  # ONE ncclAllGather per step (queries_per_step x k x 24 B per rank) + device merge
+            comm.merge_hits(d_local.data_ptr(), qps_step, k, d_global.data_ptr(), stream)
+        elif world > 1:  # gloo rehearsal
             sharded.exchange_and_merge(d_local, k, device_index=local_rank)
 
     def fence() -> None:
@@ -160,15 +224,17 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     dbg("timed region done")
+    reduce_dev = dev if world > 1 and dist.get_backend() == "nccl" else "cpu"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dbg("max over ranks done")
 
     # roofline leg: same launches, scan kernel bracketed by HIP events on its own stream
+    roof_steps = min(args.steps, 4)
     corpus.set_profiling(True)
-    for s in range(min(args.steps, 8)):
+    for s in range(roof_steps):
         base = (args.warmup + s) * qps_step
         stream = torch.cuda.current_stream().cuda_stream
         if args.mode == "batch":
@@ -181,10 +247,14 @@ def main() -> int:
     corpus.set_profiling(False)
     dbg("roofline leg done")
     avg_ms = scan_ms / max(scan_launches, 1)
-    algo_bytes = rows * dim * elem  # N*d*sizeof(elem) per query, ids/norms excluded
+    if world > 1:  # the slowest rank's kernel bounds the job
+        t = torch.tensor([avg_ms], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        avg_ms = float(t.item())
+    algo_bytes = rows * dim * elem  # N*d*sizeof(elem) per query and GPU, ids/norms excluded
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
     if mfma:  # flops = 2 * nq * N * d per batch; the dominant kernel is the prefilter GEMM
-        launches_per_batch = max(1, round(scan_launches / max(min(args.steps, 8), 1)))
+        launches_per_batch = max(1, round(scan_launches / max(roof_steps, 1)))
         flops = 2.0 * qps_step * rows * dim / launches_per_batch
         tflops = flops / (avg_ms * 1e-3) / 1e12
         mq, mf = corpus.mfma_stats()
@@ -214,10 +284,10 @@ def main() -> int:
     elif (quantize and args.mode == "single" and k <= 64 and os.environ.get("VFSX_I8_WIDE", "1") != "0"
           and (rows + 63) // 64 >= 16 * torch.cuda.get_device_properties(local_rank).multi_processor_count):
         scan_kernel_name = "scan_i8w_kernel"
-    value = qps_global * world  # shard scans per second (see module docstring)
+    traffic, traffic_source = pmc_traffic(workload, rows)
     out = {
-        "metric": "exact top-10 QPS (single-query scan; shard scans/s when row-sharded)",
-        "value": round(value, 3),
+        "metric": "exact top-10 QPS (single-query scan; queries/s against the whole row-sharded corpus)",
+        "value": round(qps_global, 3),
         "unit": "queries/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -228,17 +298,25 @@ def main() -> int:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": label, "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "k": k, "storage": "i8 (QuantizedVector, dequantized on read)" if quantize else "f32",
-                   "queries_per_step": qps_step, "mode": args.mode, "metric_fn": ["euclidean", "cosine", "simd_euclidean",
-                                                                "simd_cosine", "euclidean_i8_domain"][metric],
-                   "sharding": f"row-sharded x{world}, all-gather top-k merge" if world > 1 else "single GPU"},
-        "qps_global": round(qps_global, 3),
+        "config": config,
+        "timed_region_s": round(elapsed, 3),
+        "shard_scans_per_s": round(qps_global * world, 3),
         "hbm_gbps_aggregate": round(qps_global * algo_bytes * world / 1e9, 1),
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args.workload, rows),
+        "hbm_frac_of_aggregate_peak": round(qps_global * algo_bytes / 1e9 / HBM_PEAK_GBPS, 4),
+        "roofline": {"bound": "hbm", "achieved": round(achieved * world, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": scan_kernel_name, "avg_kernel_ms": round(avg_ms, 5),
-                     "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches)},
+                     "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": int(scan_launches),
+                     "what": ("slowest rank's average scan-kernel launch (HIP events on its stream); achieved / peak are "
+                              "the aggregate over the ranks") if world > 1 else
+                             "average scan-kernel launch (HIP events on its stream)"},
     }
+    if world > 1:
+        out["scaling_note"] = ("rows_per_gpu is fixed, so the corpus grows with N: ideal weak scaling is a constant "
+                               "value (queries/s against the whole corpus) and N x hbm_gbps_aggregate")
+        out["rccl_ranks"] = (int(vfs_amd.load().vfsx_comm_world(comm.handle)) if comm is not None else None)
+        out["collective"] = ("vfsx_comm_merge_hits: ncclAllGather (RCCL) + device merge, one per step" if comm is not None
+                             else f"torch.distributed {dist.get_backend()} rehearsal (not RCCL)")
     if metric == 4:
         out["dtype"] = "int32 dot4 on i8 (integer-domain extension) + f32 sqrt/div"
     if latency:
@@ -249,7 +327,7 @@ def main() -> int:
                      "peak_source": "MI355X_MICROARCH.md (8 TB/s HBM3E, 2.5 PFLOP/s dense bf16)"}
     if mfma:
         out["roofline"] = {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": "mfma_prefilter256_kernel", "avg_kernel_ms": round(avg_ms, 4),
                            "algorithmic_flops_per_launch": flops, "launches_timed": int(scan_launches)}
         out["mfma_queries"] = int(mq)
@@ -260,6 +338,8 @@ def main() -> int:
         out["cpu_baseline"] = cpu_baseline(args, rows, dim, quantize, metric, k)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     corpus.close()
     dbg("closed")
     if world > 1:
@@ -269,21 +349,23 @@ def main() -> int:
 
 
 def pmc_traffic(workload, rows):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/rNN/traffic.json, written by tools/summarize_profile.py); None if
-    there is no profile for this workload/size.  PMC counters cannot be read in-process."""
+    """HBM bytes per dominant-kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN/traffic.json, written by tools/summarize_profile.py) and the file it came from; (None, None) if
+    there is no profile for this workload/size.  PMC counters cannot be read in-process: this is a REPLAYED
+    figure, labelled as such by `traffic_source`."""
     import glob
     if rows != WORKLOADS[workload][0]:
-        return None
+        return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if workload in t:
-                return t[workload]["scan_hbm_bytes_per_launch"]
+                return (t[workload]["scan_hbm_bytes_per_launch"],
+                        os.path.relpath(path, ROOT) + " (replayed from the committed PMC passes, not measured in this run)")
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
 
 
 def cpu_baseline(args, rows, dim, quantize, metric, k):
@@ -295,15 +377,19 @@ def cpu_baseline(args, rows, dim, quantize, metric, k):
     x = synth.rows_f32(synth.CORPUS_SEED, 0, n, dim)
     if quantize:
         x = c_oracle.quantize(x, 127.0)
-    qs = synth.rows_f32(synth.QUERY_SEED, 0, args.cpu_sample_queries, dim)
+    qs = synth.rows_f32(synth.QUERY_SEED, 0, 4096, dim)
     c_oracle.topk_scan(x[:1024], qs[0], metric, k)  # warm
     t0 = time.perf_counter()
+    done = 0
     for q in qs:
         c_oracle.topk_scan(x, q, metric, k)
+        done += 1
+        if time.perf_counter() - t0 >= args.cpu_seconds:
+            break
     dt = time.perf_counter() - t0
-    rows_per_s = n * len(qs) / dt
+    rows_per_s = n * done / dt
     out = {"value": round(rows_per_s / rows, 4), "unit": "queries/s", "cores": 1, "kind": "port",
-           "sample": f"{len(qs)} queries x first {n} rows of the same synthetic corpus "
+           "sample": f"{done} queries x first {n} rows of the same synthetic corpus "
                      f"({dt:.1f} s of CPU), rows/s scaled to the full {rows}-row corpus",
            "rows_per_s": round(rows_per_s, 1)}
     if metric in (2, 3) and dim not in (2, 4, 8, 16, 32, 64):
@@ -320,11 +406,15 @@ def cpu_baseline(args, rows, dim, quantize, metric, k):
         threads = min(16, os.cpu_count() or 1)
     ctx = {"arithmetic": "64-lane chunked sums (not the reference's order); timing context only",
            "avx2": bool(c_oracle.lib().vfsc_have_avx2())}
-    for label, nt, nq in (("simd_chunked_1core", 1, max(8, len(qs) // 2)), ("simd_chunked_allcores", threads, len(qs))):
+    for label, nt in (("simd_chunked_1core", 1), ("simd_chunked_allcores", threads)):
         c_oracle.chunked_scan(x[:1024], qs[0], metric, k, nt)
         t0 = time.perf_counter()
-        for q in qs[:nq]:
+        nq = 0
+        for q in qs:
             c_oracle.chunked_scan(x, q, metric, k, nt)
+            nq += 1
+            if time.perf_counter() - t0 >= args.cpu_seconds / 3:
+                break
         dtc = time.perf_counter() - t0
         ctx[label] = {"value": round(n * nq / dtc / rows, 4), "unit": "queries/s", "cores": nt}
     out["context"] = ctx
