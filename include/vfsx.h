@@ -260,7 +260,7 @@ int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint
  * makes no hipMalloc / hipFree / allocating library call; the array's device address is looked up once per
  * device (hipGetSymbolAddress) by vfsx_init, or by the first call on that device -- call vfsx_init first
  * when even that must not happen on the hot path.  Limits, reported as VFSX_ERR_INVALID_VECTOR with a
- * message naming the static workspace: k <= VFSX_MAX_K as everywhere; a staged query must fit 1 MiB
+ * message naming the static workspace: k <= 1024 (one pass); a staged query must fit 1 MiB
  * (dim <= 262144 when staging applies); nq is unlimited (several launches share the workspace in stream
  * order).  Every call on one GPU uses that GPU's array: calls on the same GPU that overlap (different
  * streams without ordering, or different host threads) race on it.  Nothing in the array needs to start at
@@ -352,7 +352,10 @@ int vfsx_corpus_mfma_stats(vfsx_corpus *c, uint64_t *queries, uint64_t *fallback
 int vfsx_corpus_set_profiling(vfsx_corpus *c, int enabled);
 int vfsx_corpus_scan_time_ms(vfsx_corpus *c, double *total_ms, uint64_t *launches, int reset);
 
-#define VFSX_MAX_K 1024u
+/* Largest result_limit.  Up to 1024 hits come from one pass over the corpus; a longer result takes
+ * ceil(k / 1024) passes (each pass ranks what sorts after the previous pass's last hit).  The reference's
+ * limit is unbounded (rank.rs:129,172-173); this bound only keeps result buffers addressable. */
+#define VFSX_MAX_K (1u << 20)
 
 #ifdef __cplusplus
 }

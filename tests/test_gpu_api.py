@@ -121,8 +121,10 @@ def test_error_behaviour():
     assert "Query vector dimension mismatch" in str(e.value)
     with pytest.raises(vfs_amd.VfsxError):
         c.search_batch(np.zeros(8, np.float32), 0, 0)
+    ids, dist, cnt = c.search_batch(np.zeros(8, np.float32), 5000, 0)  # beyond one pass: served (empty corpus: 0 hits)
+    assert cnt[0] == 0
     with pytest.raises(vfs_amd.VfsxError):
-        c.search_batch(np.zeros(8, np.float32), 5000, 0)
+        c.search_batch(np.zeros(8, np.float32), (1 << 20) + 1, 0)  # VFSX_MAX_K
     with pytest.raises(vfs_amd.VfsxError):
         c.search_batch(np.zeros(8, np.float32), 5, 9)
     # empty corpus: zero hits, no error

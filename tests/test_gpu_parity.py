@@ -163,3 +163,31 @@ def test_subnormal_and_huge_magnitudes(oracle, magnitude, metric):
         oi, od, _ = oracle.topk_scan(rows, qq.astype(np.float32), metric, 10)
         assert (gi[qi] == oi).all() and (_bits(gd[qi]) == _bits(od)).all()
     c.close()
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_result_limit_beyond_one_pass(oracle, quantize):
+    """The reference's result_limit is unbounded (rank.rs:129,172-173).  Up to 1024 hits come from one pass; a longer
+    result takes ceil(k / 1024) passes, pass p ranking what sorts after pass p-1's last (distance, row).  Saturated
+    int8 rows make thousands of exact ties straddle the pass boundaries."""
+    import vfs_amd
+    rng = np.random.default_rng(61)
+    n, d = 9000, 24
+    if quantize:
+        base = rng.uniform(-10, 10, (40, d)).round(4).astype(np.float32)
+        rows = oracle.quantize(base[rng.integers(0, 40, n)], 127.0)  # 40 distinct rows: ties everywhere
+    else:
+        rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (3, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    c.append(rows)
+    kw = {"scale": 127.0} if quantize else {}
+    for k in (1025, 2048, 3000, 9000, 12000):  # 12000 > rows: every row comes back, ranked
+        for metric in (0, 1):
+            ids, dist, cnt = c.search_batch(queries, k, metric)
+            for qi in range(len(queries)):
+                oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k, **kw)
+                assert cnt[qi] == len(oi) == min(k, n)
+                assert (ids[qi, :cnt[qi]] == oi).all()
+                assert (_bits(dist[qi, :cnt[qi]]) == _bits(od)).all()
+    c.close()

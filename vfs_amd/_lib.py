@@ -19,7 +19,7 @@ ERR_INTERNAL = -6
 ERR_NO_DEVICE = -7
 
 F32, I8 = 0, 1
-MAX_K = 1024
+MAX_K = 1 << 20  # VFSX_MAX_K; results beyond 1024 hits take several corpus passes
 
 # every symbol include/vfsx.h declares
 SYMBOLS = (

@@ -142,7 +142,7 @@ struct vfsx_corpus {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
 
     // search workspace
-    DeviceBuf<uint64_t> lists;
+    DeviceBuf<uint64_t> lists, cursor;
     DeviceBuf<float> q_in, q_pad;
     DeviceBuf<vfsx_hit> hits;
     DeviceBuf<uint64_t> row_idx;
@@ -410,26 +410,14 @@ struct ScanWorkspace {
     size_t q_stage_elems;
 };
 
-// the exact scan: enqueue the whole search on `s`; no host synchronisation
-void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
-                         vfsx_hit *d_hits, hipStream_t s, const ScanWorkspace *ws = nullptr)
+// One pass of the exact scan (k <= kMaxKPerPass hits per query): enqueue scan + select on `s`, no host
+// synchronisation.  Query q's hits go to d_hits[q * out_stride + out_off ..]; with cursor_in the pass ranks only
+// what sorts after each query's cursor, with cursor_out it leaves the next pass's cursors.
+void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric, vfsx_hit *d_hits,
+                     uint32_t out_stride, uint32_t out_off, const uint64_t *cursor_in, uint64_t *cursor_out,
+                     hipStream_t s, const ScanWorkspace *ws)
 {
-    if (metric < VFSX_EUCLIDEAN || metric > VFSX_EUCLIDEAN_I8DOMAIN)
-        fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
     const bool i8dom = metric == VFSX_EUCLIDEAN_I8DOMAIN;
-    if (i8dom && c->dtype != VFSX_I8)
-        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain distance needs a quantized (int8) corpus");
-    if (i8dom && c->dim > 32768u)
-        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain distance supports dim <= 32768");
-    if (k == 0 || k > VFSX_MAX_K)
-        fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
-    if (nq == 0)
-        return;
-    if (!d_queries || !d_hits)
-        fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
-    use_device(c);
-    if (c->prof_used > 4096)
-        prof_collect(c);
     const bool profiling = c->profiling && !ws; // event creation allocates: never on the no-allocation path
 
     // queries the kernels cannot read in place are staged: quantized and packed for the integer-domain
@@ -487,7 +475,7 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
     }
     // single-query int8 scans of big corpora: 16-wave workgroups around one 64 KiB table (vfsx_kernels.hip)
     const bool wide = c->dtype == VFSX_I8 && !i8dom && nq_per_pass == 1 && k <= 64u && c->i8_wide != 0 &&
-                      n_rowblocks >= 16u * c->n_cus;
+                      n_rowblocks >= 16u * c->n_cus && !cursor_in; // (only scan_kernel knows about cursors)
     const uint32_t wg_waves = wide ? vfsx::kWideScanWaves : 4u;
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + wg_waves - 1u) / wg_waves,
                                          wide ? c->n_cus * c->i8_wide : c->max_blocks);
@@ -534,6 +522,7 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
             a.q_stride = q_stride;
             a.k = k;
             a.n_lists = grid_x;
+            a.cursor = cursor_in ? cursor_in + q0 : nullptr;
             size_t slot = 0;
             if (profiling)
                 prof_begin(c, s, slot);
@@ -549,12 +538,55 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
         SelectArgs sa{};
         sa.lists = lists;
         sa.ids = c->explicit_ids ? c->d_ids : nullptr;
-        sa.out = d_hits + (size_t)q0 * k;
+        sa.out = d_hits + (size_t)q0 * out_stride + out_off;
         sa.row_base = c->row_base;
         sa.id_base = c->id_base;
         sa.n_lists = grid_x;
         sa.k = k;
+        sa.out_stride = out_stride;
+        sa.cursor_out = cursor_out ? cursor_out + q0 : nullptr;
         HIP_CHECK(vfsx::launch_select(sa, qn, s));
+    }
+}
+
+// the exact scan: enqueue the whole search on `s`; no host synchronisation
+void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
+                         vfsx_hit *d_hits, hipStream_t s, const ScanWorkspace *ws = nullptr)
+{
+    if (metric < VFSX_EUCLIDEAN || metric > VFSX_EUCLIDEAN_I8DOMAIN)
+        fail(VFSX_ERR_INVALID_VECTOR, "unknown distance method");
+    const bool i8dom = metric == VFSX_EUCLIDEAN_I8DOMAIN;
+    if (i8dom && c->dtype != VFSX_I8)
+        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain distance needs a quantized (int8) corpus");
+    if (i8dom && c->dim > 32768u)
+        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain distance supports dim <= 32768");
+    if (k == 0 || k > VFSX_MAX_K)
+        fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
+    if (nq == 0)
+        return;
+    if (!d_queries || !d_hits)
+        fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
+    use_device(c);
+    if (c->prof_used > 4096)
+        prof_collect(c);
+    constexpr uint32_t P = vfsx::kMaxKPerPass;
+    if (k <= P) {
+        exact_scan_pass(c, d_queries, nq, k, metric, d_hits, k, 0, nullptr, nullptr, s, ws);
+        return;
+    }
+    // result_limit beyond one pass (the reference's limit is unbounded, rank.rs:129,172-173): ceil(k / 1024)
+    // passes over the corpus, pass p ranking what sorts strictly after the (unique) composite key its
+    // predecessor ended on -- the concatenation is the ranking a single longer list would give
+    if (ws)
+        fail(VFSX_ERR_INVALID_VECTOR, "vfsx_search_device_noalloc: k is limited to " + std::to_string(P) +
+                                          " (the passes of a longer result need a cursor buffer)");
+    if (i8dom)
+        fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain extension supports k <= " + std::to_string(P));
+    c->cursor.reserve(nq);
+    for (uint32_t off = 0; off < k; off += P) {
+        const uint32_t kp = std::min(P, k - off);
+        exact_scan_pass(c, d_queries, nq, kp, metric, d_hits, k, off, off ? c->cursor.p : nullptr,
+                        off + kp < k ? c->cursor.p : nullptr, s, nullptr);
     }
 }
 
@@ -946,6 +978,7 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->cand.release();
     c->sel.release();
     c->lists.release();
+    c->cursor.release();
     c->q_in.release();
     c->q_pad.release();
     c->hits.release();

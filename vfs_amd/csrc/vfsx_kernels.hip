@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
     const float *__restrict__ queries, const float *__restrict__ lut, uint64_t *__restrict__ lists,
     uint32_t n_rows, uint32_t d_chunks, uint32_t n_rowblocks, uint32_t q_stride, uint32_t k,
-    uint32_t n_lists, uint32_t nq)
+    uint32_t n_lists, uint32_t nq, const uint64_t *__restrict__ cursor)
 {
     extern __shared__ __align__(16) uint64_t dyn_lds[];
     __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
@@ -90,6 +90,12 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
         qn[n] = 0.0f;
+    // result_limit beyond one pass (k > 1024): this pass ranks only what sorts strictly after the query's
+    // cursor, the last composite key of the previous pass (keys are unique, so the passes tile the ranking)
+    uint64_t cur[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        cur[n] = cursor ? cursor[min(q0 + (uint32_t)n, nq - 1u)] : 0ull;
 
     // distance of row (64 blk + lane) from its finished accumulators, offered to the wave's lists
     auto finish_rowblock = [&](uint32_t blk, Acc(&acc)[NQ]) {
@@ -109,6 +115,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                     dist = f_sub(1.0f, f_div(acc[n].a, den));
                 }
                 comp = ((uint64_t)dist_key(dist) << 32) | row;
+                if (cursor && comp <= cur[n])
+                    comp = kSentinel;
             }
             top[n].offer(comp);
         }
@@ -328,7 +336,8 @@ template <typename TopK, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__restrict__ lists,
                                                             const uint64_t *__restrict__ ids,
                                                             vfsx_hit *__restrict__ out, uint64_t row_base,
-                                                            uint64_t id_base, uint32_t n_lists, uint32_t k)
+                                                            uint64_t id_base, uint32_t n_lists, uint32_t k,
+                                                            uint32_t out_stride, uint64_t *__restrict__ cursor_out)
 {
     constexpr uint32_t BLOCK = 64u * WAVES;
     extern __shared__ __align__(16) uint64_t dyn_lds[];
@@ -397,8 +406,10 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
                 h.row = row_base + r;
                 h.id = ids ? ids[r] : id_base + r;
             }
-            out[(size_t)qi * k + j] = h;
+            out[(size_t)qi * out_stride + j] = h;
         }
+        if (cursor_out && lane == 0)
+            cursor_out[qi] = mine[k - 1]; // kSentinel when fewer than k rows were left: later passes find nothing
     }
 }
 
@@ -723,11 +734,11 @@ static hipError_t launch_scan_v(const ScanArgs &a, uint32_t nq, uint32_t grid_x,
     if (a.k <= kMaxRegisterK) {
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists, nq);
+                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
     } else {
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists, nq);
+                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
     }
     return hipGetLastError();
 }
@@ -821,12 +832,12 @@ hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)
         constexpr int W = 16;
         const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
         hipLaunchKernelGGL((select_kernel<WaveTopKReg, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
-                           a.out, a.row_base, a.id_base, a.n_lists, a.k);
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k, a.cursor_out);
     } else {
         constexpr int W = 4;
         const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
         hipLaunchKernelGGL((select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
-                           a.out, a.row_base, a.id_base, a.n_lists, a.k);
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k, a.cursor_out);
     }
     return hipGetLastError();
 }
