@@ -212,3 +212,47 @@ def test_rccl_collective_and_device_merge_single_rank():
                        timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "OK rccl" in r.stdout
+
+
+def test_implicit_ids_continue_after_the_largest_explicit_id(oracle):
+    """A store whose ids are not its row positions (e.g. loaded from a log with gaps): rows appended without ids
+    continue at max(id) + 1 (next_id, storage_manager.rs:126-130), never at row position + 1."""
+    import vfs_amd
+    rng = np.random.default_rng(12)
+    rows = rng.uniform(-1, 1, (6, 8)).astype(np.float32)
+    c = vfs_amd.Corpus(8)
+    c.append(rows[:3], ids=np.array([10, 50, 20], dtype=np.uint64))
+    c.append(rows[3:5])          # -> 51, 52
+    c.append(rows[5:], ids=np.array([7], dtype=np.uint64))
+    assert c.get_ids(range(6)).tolist() == [10, 50, 20, 51, 52, 7]
+    ids, dist, cnt = c.search_batch(rows[4], 1, 0)
+    assert ids[0, 0] == 52 and dist[0, 0] == 0.0
+    c.close()
+
+
+def test_searches_on_different_streams_share_the_workspaces_safely(oracle):
+    """vfsx_search_device on two streams without any synchronisation in between: the second call's stream is made
+    to wait for the first call's kernels (they share the corpus' list workspace), so both results are right."""
+    import torch
+    import vfs_amd
+    from vfs_amd import sharded
+    rng = np.random.default_rng(13)
+    n, d, k = 400000, 64, 10
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    q = rng.uniform(-1, 1, (2, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    dq = torch.from_numpy(q).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = torch.zeros((40, k, 6), dtype=torch.int32, device="cuda")
+    for i in range(40):  # alternate streams, never synchronise
+        st = s1 if i % 2 == 0 else s2
+        c.search_device(dq[i % 2].data_ptr(), 1, k, i % 2, outs[i].data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    ids, dist, cnt = sharded.hits_to_arrays(outs)
+    want = [oracle.topk_scan(rows, q[m], m, k) for m in (0, 1)]
+    for i in range(40):
+        oi, od, _ = want[i % 2]
+        assert (ids[i] == oi).all() and (bits(dist[i]) == bits(od)).all()
+    c.close()

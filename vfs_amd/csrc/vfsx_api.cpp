@@ -128,6 +128,7 @@ struct vfsx_corpus {
     uint64_t id_base = 1;  // implicit ids: id_base + local row (storage_manager.rs:76)
     bool explicit_ids = false;
     std::vector<uint64_t> ids_host; // only when explicit_ids
+    uint64_t max_id = 0;            // largest explicit id stored (implicit continuation: max_id + 1)
 
     uint4 *d_corpus = nullptr;
     float *d_norms = nullptr;
@@ -135,6 +136,11 @@ struct vfsx_corpus {
     float *d_lut = nullptr;
 
     hipStream_t stream = nullptr; // ingest + host-API searches
+    // the search workspaces below are shared by every search on this corpus: searches on different streams are
+    // chained (the new stream waits for what the previous one had enqueued) instead of left to race
+    hipStream_t last_search_stream = nullptr;
+    bool searched = false;
+    hipEvent_t search_done = nullptr;
     // ingest staging (pinned host + device), double buffered
     size_t stage_bytes = 0;
     void *h_stage[2] = {nullptr, nullptr};
@@ -305,18 +311,28 @@ void staging_copy(void *dst, const void *src, size_t bytes)
         th.join();
 }
 
-// make ids explicit: materialise the implicit run for rows already stored
+// make ids explicit: materialise the implicit run for rows already stored.  Host and device state change only
+// after every allocation and copy has succeeded.
 void make_ids_explicit(vfsx_corpus *c)
 {
     if (c->explicit_ids)
         return;
-    c->ids_host.resize(c->n_rows);
+    std::vector<uint64_t> ids(c->n_rows);
     for (uint64_t r = 0; r < c->n_rows; ++r)
-        c->ids_host[r] = c->id_base + r;
+        ids[r] = c->id_base + r;
+    uint64_t *d_ids = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_ids, std::max<uint64_t>(c->capacity, 64) * sizeof(uint64_t)));
+    if (c->n_rows) {
+        const hipError_t e = hipMemcpy(d_ids, ids.data(), c->n_rows * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_ids);
+            HIP_CHECK(e);
+        }
+    }
+    c->ids_host.swap(ids);
+    c->d_ids = d_ids;
+    c->max_id = c->n_rows ? c->id_base + c->n_rows - 1 : 0;
     c->explicit_ids = true;
-    HIP_CHECK(hipMalloc((void **)&c->d_ids, std::max<uint64_t>(c->capacity, 64) * sizeof(uint64_t)));
-    if (c->n_rows)
-        HIP_CHECK(hipMemcpy(c->d_ids, c->ids_host.data(), c->n_rows * sizeof(uint64_t), hipMemcpyHostToDevice));
 }
 
 // mode 0: f32 rows -> f32 corpus, 1: i8 -> i8, 2: f32 -> i8 (quantize on device)
@@ -352,15 +368,26 @@ void append_impl(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t
     }
     HIP_CHECK(vfsx::launch_row_norms(c->dtype, c->d_corpus, c->d_chunks, c->d_lut, c->n_rows, n, c->d_norms,
                                      c->stream));
+    // the new rows' ids: staged here, committed to ids_host / max_id / n_rows only once the device work is known
+    // to have succeeded (a failed append leaves the corpus exactly as it was; rows past n_rows are never read)
+    std::vector<uint64_t> new_ids;
+    uint64_t new_max = c->max_id;
     if (c->explicit_ids) {
-        const size_t old = c->ids_host.size();
-        c->ids_host.resize(old + n);
-        for (uint64_t i = 0; i < n; ++i)
-            c->ids_host[old + i] = ids ? ids[i] : (c->id_base + c->n_rows + i);
-        HIP_CHECK(hipMemcpyAsync(c->d_ids + c->n_rows, c->ids_host.data() + old, n * sizeof(uint64_t),
-                                 hipMemcpyHostToDevice, c->stream));
+        new_ids.resize(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            // no ids given on a store that has explicit ones: continue after the largest id present
+            // (next_id semantics, storage_manager.rs:126-130), never by row position
+            new_ids[i] = ids ? ids[i] : new_max + 1;
+            new_max = std::max(new_max, new_ids[i]);
+        }
+        HIP_CHECK(hipMemcpyAsync(c->d_ids + c->n_rows, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                 c->stream));
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->explicit_ids) {
+        c->ids_host.insert(c->ids_host.end(), new_ids.begin(), new_ids.end());
+        c->max_id = new_max;
+    }
     c->n_rows += n;
 }
 
@@ -769,6 +796,21 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     }
 }
 
+// A search on a stream other than the previous search's: make it wait for everything that search enqueued
+// (both use the corpus' workspaces).  Costs nothing while the caller stays on one stream.
+void chain_search_stream(vfsx_corpus *c, hipStream_t s)
+{
+    if (c->searched && c->last_search_stream != s) {
+        use_device(c);
+        if (!c->search_done)
+            HIP_CHECK(hipEventCreateWithFlags(&c->search_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(c->search_done, c->last_search_stream));
+        HIP_CHECK(hipStreamWaitEvent(s, c->search_done, 0));
+    }
+    c->last_search_stream = s;
+    c->searched = true;
+}
+
 void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
                         vfsx_hit *d_hits, hipStream_t s)
 {
@@ -780,6 +822,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         return;
     if (!d_queries || !d_hits)
         fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
+    chain_search_stream(c, s);
     // the reference's four metrics; the integer-domain extension has its own kernel
     const bool metric_ok = metric != VFSX_EUCLIDEAN_I8DOMAIN;
     const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 && c->dim <= vfsx::kMfmaMaxDim &&
@@ -952,6 +995,8 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
+    if (c->search_done)
+        (void)hipEventDestroy(c->search_done);
     for (auto &pe : c->prof_events) {
         (void)hipEventDestroy(pe.first);
         (void)hipEventDestroy(pe.second);
