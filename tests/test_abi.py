@@ -89,3 +89,64 @@ def test_split_rows_contiguous():
     assert sharded.split_rows(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert sharded.split_rows(100_000_000, 8)[7] == (87_500_000, 100_000_000)
     assert sharded.split_rows(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+# ---- the Rust crate's extern "C" block must declare every entry point of include/vfsx.h with matching types ----
+
+_C_TO_RUST = {
+    "void": "()", "int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64",
+    "const char *": "*const c_char", "char *": "*mut c_char", "void *": "*mut c_void", "const void *": "*const c_void",
+    "const float *": "*const f32", "float *": "*mut f32", "double *": "*mut f64",
+    "const uint64_t *": "*const u64", "uint64_t *": "*mut u64", "uint32_t *": "*mut u32",
+    "vfsx_corpus *": "*mut VfsxCorpus", "const vfsx_corpus *": "*const VfsxCorpus",
+    "vfsx_comm *": "*mut VfsxComm", "const vfsx_comm *": "*const VfsxComm",
+    "vfsx_hit *": "*mut VfsxHit", "const vfsx_hit *": "*const VfsxHit", "vfsx_log_info *": "*mut VfsxLogInfo",
+}
+
+
+def _c_type(decl: str) -> str:
+    """'const float *queries' -> 'const float *' ; 'uint32_t nq' -> 'uint32_t' ; 'void' -> 'void'."""
+    decl = " ".join(decl.split())
+    if decl == "void":
+        return "void"
+    m = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)$", decl)  # strip the parameter name
+    t = m.group(1).strip() if m and m.group(1).strip() else decl
+    return re.sub(r"\s*\*\s*", " *", t).strip()
+
+
+def header_prototypes():
+    src = open(os.path.join(ROOT, "include", "vfsx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^([A-Za-z_][A-Za-z0-9_ \*]*?)\b(vfsx_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.M | re.S):
+        ret = re.sub(r"\s*\*\s*", " *", " ".join(m.group(1).split())).strip()
+        args = [_c_type(a) for a in m.group(3).split(",")]
+        protos[m.group(2)] = (ret, [] if args == ["void"] else args)
+    return protos
+
+
+def rust_prototypes():
+    src = open(os.path.join(ROOT, "rust", "vfsx", "src", "lib.rs")).read()
+    block = src[src.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    block = re.sub(r"//[^\n]*", "", block)
+    protos = {}
+    for m in re.finditer(r"pub fn (vfsx_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        args = [a.split(":", 1)[1].strip() for a in m.group(2).split(",") if a.strip()]
+        protos[m.group(1)] = ((m.group(3) or "()").strip(), [" ".join(a.split()) for a in args])
+    return protos
+
+
+def test_rust_crate_declares_every_entry_point_with_matching_types():
+    c, r = header_prototypes(), rust_prototypes()
+    assert set(c) == set(_lib.SYMBOLS)  # the parser sees what the library exports
+    assert set(r) == set(c), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name, (ret, args) in c.items():
+        want = (_C_TO_RUST[ret], [_C_TO_RUST[a] for a in args])
+        assert r[name] == want, (name, r[name], want)
+
+
+def test_cxx_mirror_and_ctypes_cover_the_sharded_entry_points():
+    hpp = open(os.path.join(ROOT, "vfs_amd", "cxx", "vfsx_ranker.hpp")).read()
+    for sym in ("vfsx_comm_unique_id", "vfsx_comm_init", "vfsx_comm_destroy", "vfsx_search_sharded_host"):
+        assert sym in hpp, sym
