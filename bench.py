@@ -330,6 +330,8 @@ def main(argv=None) -> int:
                            "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": "mfma_prefilter256_kernel", "avg_kernel_ms": round(avg_ms, 4),
                            "algorithmic_flops_per_launch": flops, "launches_timed": int(scan_launches)}
+        for key in ("hbm_gbps_aggregate", "hbm_frac_of_aggregate_peak", "shard_scans_per_s"):
+            out.pop(key, None)  # HBM figures describe the single-query scan, not a matrix-core batch
         out["mfma_queries"] = int(mq)
         out["mfma_fallback_queries"] = int(mf)
         out["dtype"] = "bf16 MFMA prefilter + f32 exact re-score"
