@@ -56,6 +56,43 @@ def test_mfma_batch_equals_exact_int8(oracle):
     c.close()
 
 
+@pytest.mark.parametrize("d,n,scale", [(1, 20000, 127.0), (15, 30000, 127.0), (17, 16400, 127.0), (200, 25000, 127.0),
+                                       (256, 16384, 127.0), (257, 17000, 64.0), (768, 20000, 127.0),
+                                       (48, 66000, -3.5)])
+@pytest.mark.parametrize("metric", [1, 0])
+def test_mfma_int8_reads_the_rb64_corpus(oracle, d, n, scale, metric):
+    """int8 stores have no mirror: the prefilter multiplies the rb64 corpus itself with int8-quantized queries
+    (v_mfma_i32_32x32x32_i8).  Dimensions off the chunk (16) and off the K round (256), a corpus ending inside a row
+    tile (K padding and missing row-blocks read past the rows / the allocation), capacities that leave no slack,
+    other scale factors (the store holds byte / scale)."""
+    import vfs_amd
+    rng = np.random.default_rng(d * 3 + n + metric)
+    rows = rng.integers(-128, 128, (n, d), dtype=np.int8)
+    rows[np.abs(rows.astype(np.int32)).sum(axis=1) == 0, 0] = 1
+    queries = rng.uniform(-1, 1, (70, d)).astype(np.float32)
+    queries[3] *= 1e-3
+    queries[4, : max(1, d // 2)] = 0.0
+    if d > 1:
+        queries[5] = 0.0
+        queries[5, d - 1] = -2.0  # one-hot: quantizes exactly
+    c = vfs_amd.Corpus(d, quantize=True, scale=scale, capacity_rows=n)
+    c.append(rows)
+    c.enable_mfma(True)
+    c.mfma_stats(reset=True)
+    ids_m, dist_m, cnt_m = c.search_batch(queries, 10, metric)
+    nq_m, fb = c.mfma_stats()
+    assert nq_m == len(queries)
+    if d >= 48 and metric == 1:
+        assert fb <= len(queries) // 2
+    c.enable_mfma(False)
+    ids_e, dist_e, cnt_e = c.search_batch(queries, 10, metric)
+    assert (cnt_m == cnt_e).all() and (ids_m == ids_e).all() and (bits(dist_m) == bits(dist_e)).all()
+    for qi in (0, 3, 5):
+        oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, 10, scale=scale)
+        assert (ids_m[qi] == oi).all() and (bits(dist_m[qi]) == bits(od)).all()
+    c.close()
+
+
 def test_mfma_clustered_corpus_forces_fallbacks(oracle):
     """Near-duplicate rows packed next to each other: many rows of one candidate list sit above
     the safety margin, the check must flag those queries, and the exact scan must answer them."""

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvfsx.so")
+LIB_PATH = os.environ.get("VFSX_LIB_PATH") or os.path.join(_HERE, "lib", "libvfsx.so")  # (override: A/B of builds)
 
 # vfsx_status (include/vfsx.h), mirroring VFSError (vfs/src/vfs/err.rs:10-16)
 OK = 0

@@ -177,8 +177,9 @@ struct vfsx_corpus {
     size_t mirror_bytes = 0;
     uint32_t *d_mirror_stats = nullptr; // device: [0] a row norm outside the path's range exists, [1] R_x (vfsx_mfma.hip)
     float *d_rn2 = nullptr;      // [mirror rows padded] float2 (b, b^2 (1 - gamma)) for Euclidean batches
+    float *d_inv_rn = nullptr;   // int8 stores: [same rows] 1 / (scale b); the rb64 corpus is the MFMA operand, no mirror
     size_t rn2_rows = 0;
-    DeviceBuf<float> q_norm, q_eps;
+    DeviceBuf<float> q_norm, q_eps, q_scale;
     DeviceBuf<uint32_t> fb_idx;  // exact fallback of flagged queries: their indices, compacted copies, hits
     DeviceBuf<float> fb_queries;
     DeviceBuf<vfsx_hit> fb_hits;
@@ -623,7 +624,10 @@ void free_mirror(vfsx_corpus *c)
         (void)hipFree(c->d_mirror);
     if (c->d_rn2)
         (void)hipFree(c->d_rn2);
+    if (c->d_inv_rn)
+        (void)hipFree(c->d_inv_rn);
     c->d_rn2 = nullptr;
+    c->d_inv_rn = nullptr;
     c->rn2_rows = 0;
     c->d_mirror = nullptr;
     c->mirror_rows = 0;
@@ -634,12 +638,14 @@ void free_mirror(vfsx_corpus *c)
 // sequential sums of d terms, the row norm b vs ||x||, the query norm a vs ||q||, and the epilogue's roundings
 float mfma_gamma(uint32_t k_pad) { return ((float)k_pad + 32.0f) * 0x1p-23f; }
 
-// (re)build the bf16 mirror when rows were appended since it was made
+// (re)build what the batch path keeps per row when rows were appended since: f32 stores, the bf16 mirror; int8
+// stores, only the per-row factors (the prefilter multiplies the rb64 corpus itself)
 void ensure_mirror(vfsx_corpus *c, hipStream_t s)
 {
-    if (c->mirror_rows == c->n_rows && c->d_mirror)
+    const bool i8 = c->dtype == VFSX_I8;
+    if (c->mirror_rows == c->n_rows && c->d_rn2)
         return;
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
     if (g.mirror_bytes > c->mirror_bytes) {
         free_mirror(c);
         HIP_CHECK(hipMalloc((void **)&c->d_mirror, g.mirror_bytes));
@@ -648,18 +654,25 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
     if (!c->d_mirror_stats)
         HIP_CHECK(hipMalloc((void **)&c->d_mirror_stats, 2 * sizeof(uint32_t)));
     HIP_CHECK(hipMemsetAsync(c->d_mirror_stats, 0, 2 * sizeof(uint32_t), s));
-    HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror, (uint32_t)c->n_rows,
-                                       c->dim, c->d_chunks, g, c->d_mirror_stats, s));
+    if (!i8)
+        HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror,
+                                           (uint32_t)c->n_rows, c->dim, c->d_chunks, g, c->d_mirror_stats, s));
     const size_t n_pad = (size_t)g.n_rowtiles * 256u; // Euclidean batches: (b, b^2 (1 - gamma)) per row
     if (n_pad > c->rn2_rows) {
         if (c->d_rn2)
             (void)hipFree(c->d_rn2);
+        if (c->d_inv_rn)
+            (void)hipFree(c->d_inv_rn);
         c->d_rn2 = nullptr;
+        c->d_inv_rn = nullptr;
+        c->rn2_rows = 0;
         HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
+        if (i8)
+            HIP_CHECK(hipMalloc((void **)&c->d_inv_rn, n_pad * sizeof(float)));
         c->rn2_rows = n_pad;
     }
     HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad, mfma_gamma(g.k_pad),
-                                              c->d_rn2, s));
+                                              c->d_rn2, c->d_inv_rn, c->scale, c->d_mirror_stats, s));
     uint32_t bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_stats, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -675,7 +688,9 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 {
     use_device(c);
     ensure_mirror(c, s);
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim);
+    const bool i8 = c->dtype == VFSX_I8;
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
+    const size_t qm_elem = i8 ? 1u : 2u; // query mirror: int8 or bf16
     // first-pass candidates per query; queries with more rows above their safety margin are decided again from
     // 256 candidates in the second device pass below (C4, k = 10: 64 -> 68.3 ms per batch, 128 -> 70.6 ms, no
     // query left for the exact scan either way)
@@ -700,23 +715,37 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     q_round = std::min<uint32_t>(q_round, (nq + 255u) / 256u * 256u);
     c->cand.reserve((size_t)q_round * 3u * g.n_lists);
     c->sel.reserve((size_t)q_round * 256u); // kp in the first pass, 256 in the second
-    c->q_mirror.reserve((size_t)q_round * g.k_pad * 2u);
+    c->q_mirror.reserve((size_t)q_round * g.k_pad * qm_elem);
     c->q_bad.reserve(nq);
     c->q_norm.reserve(nq);
     c->q_eps.reserve(nq);
+    if (i8)
+        c->q_scale.reserve(nq);
     c->q_flags.reserve(nq);
     c->h_flags.assign(nq, 0);
 
     for (uint32_t q0 = 0; q0 < nq; q0 += q_round) {
         const uint32_t qn = std::min(q_round, nq - q0);
         const uint32_t qn_pad = (qn + 255u) / 256u * 256u;
-        HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * 2u, s));
-        HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
-                                               c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0, c->d_mirror_stats, s));
+        HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * qm_elem, s));
+        if (i8)
+            HIP_CHECK(vfsx::launch_mfma_query_prep_i8(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
+                                                      c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0,
+                                                      c->q_scale.p + q0, s));
+        else
+            HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
+                                                   c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0,
+                                                   c->d_mirror_stats, s));
         size_t slot = 0;
         prof_begin(c, s, slot);
-        HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
-                                              c->d_rn2, c->q_norm.p + q0, c->q_eps.p + q0, s));
+        if (i8)
+            HIP_CHECK(vfsx::launch_mfma_prefilter_i8(c->d_corpus, c->d_chunks, c->corpus_bytes(c->capacity),
+                                                     c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
+                                                     c->d_rn2, c->d_inv_rn, c->q_norm.p + q0, c->q_eps.p + q0,
+                                                     c->q_scale.p + q0, c->scale, s));
+        else
+            HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn,
+                                                  euclid, c->d_rn2, c->q_norm.p + q0, c->q_eps.p + q0, s));
         prof_end(c, s, slot);
         HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, kp, nullptr, s));
         vfsx::MfmaRescoreArgs a{};
@@ -735,6 +764,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.k = k;
         a.kp = kp;
         a.q_eps = c->q_eps.p + q0;
+        a.q_scale = i8 ? c->q_scale.p + q0 : nullptr;
         a.row_base = c->row_base;
         a.id_base = c->id_base;
         a.strip_tiles = g.strip_tiles;
@@ -1016,6 +1046,7 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->q_bad.release();
     c->q_norm.release();
     c->q_eps.release();
+    c->q_scale.release();
     c->fb_idx.release();
     c->fb_queries.release();
     c->fb_hits.release();

@@ -96,16 +96,16 @@ hipError_t launch_scan_i8dom(const ScanArgs &a, uint32_t nq, uint32_t grid_x, bo
 
 // ---- many-query batches on the matrix cores (vfsx_mfma.hip) ---------------------------------
 struct MfmaGeometry {
-    uint32_t k_pad;      // dim rounded up to 128
-    uint32_t KS;         // k_pad / 16 fragment k-steps
+    uint32_t k_pad;      // dim rounded up to the ring round: 128 (bf16 mirror) or 256 (int8 stores)
+    uint32_t KS;         // fragment k-slices: k_pad / 16 (bf16) or k_pad / 32 (int8)
     uint32_t n_rowtiles; // ceil(n_rows / 256)
     uint32_t strip_tiles; // row tiles per strip (1..16)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
     uint32_t n_lists;    // candidate lists per query = 4 * n_strips
-    size_t mirror_bytes; // bf16 mirror of the corpus (rows padded to 256)
+    size_t mirror_bytes; // bf16 mirror of the corpus (rows padded to 256); 0 for int8 stores (rb64 is the operand)
 };
 constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor assumes K <= 32768
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim);
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8);
 float mfma_f32_slack(uint32_t k_pad);
 
 struct MfmaRescoreArgs {
@@ -126,6 +126,7 @@ struct MfmaRescoreArgs {
     const float *q_norm;  // [nq] the scalar each query mirror row was divided by
     float gamma;          // relative f32 error allowance of the Euclidean check
     int only_flagged;     // != 0: second pass, only queries whose flags[q] is set (they are re-decided)
+    const float *q_scale; // int8 stores: [nq] s_q, the query's quantization step (nullptr on the bf16 path)
 };
 // stats[2] (device): [0] != 0: a row norm outside the path's range; [1]: R_x, the mirror's largest rounding
 // residual (float bits).  Both zeroed by the caller before the two launches.
@@ -134,9 +135,17 @@ hipError_t launch_mfma_mirror(int dtype, const uint4 *corpus, const float *row_n
                               uint32_t *stats, hipStream_t s);
 hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
                                   int *q_bad, float *q_norm, float *q_eps, const uint32_t *stats, hipStream_t s);
-// out[n_pad] float2 = (b, b^2 (1 - gamma)), zero beyond n_rows
+// out[n_pad] float2 = (b, b^2 (1 - gamma)), zero beyond n_rows; inv[n_pad] (or nullptr) = 1 / (i8_scale b); stats[0]
+// is raised for a norm outside the path's range
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
-                                     hipStream_t s);
+                                     float *inv, float i8_scale, uint32_t *stats, hipStream_t s);
+// int8 stores: no mirror -- the prefilter reads the rb64 corpus; the queries are quantized per batch
+hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
+                                     int *q_bad, float *q_norm, float *q_eps, float *q_scale, hipStream_t s);
+hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint64_t corpus_bytes, const void *q_mirror,
+                                    float *cand, uint32_t n_rows, const MfmaGeometry &g, uint32_t nq, int euclid,
+                                    const float *rn2, const float *inv_rn, const float *q_norm, const float *q_eps,
+                                    const float *q_scale, float i8_scale, hipStream_t s);
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
                                  const float *q_norm, const float *q_eps, hipStream_t s);

@@ -158,18 +158,32 @@ __global__ void mfma_residual_kernel(const uint4 *__restrict__ corpus, const flo
 }
 
 // ---- Euclidean batches: per-row (b, b^2 (1 - gamma)) with b = the f32 row norm the mirror used ----
+// inv (int8 stores, may be null): 1 / (scale b) = 1 / ||stored bytes||, the factor that turns the integer dot product
+// into the cosine up to the query's own scale (the store holds x = byte / scale, vector.rs:138); stats[0] is raised
+// for a norm outside the path's range (the bf16 mirror kernel does the same).
 __global__ void mfma_rownorm_pairs_kernel(const float *__restrict__ row_norms, uint32_t n_rows, uint32_t n_pad,
-                                          float gamma, float2 *__restrict__ out)
+                                          float gamma, float2 *__restrict__ out, float *__restrict__ inv,
+                                          float i8_scale, uint32_t *__restrict__ stats)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_pad)
         return;
-    float b = 0.0f, bsq = 0.0f;
+    float b = 0.0f, bsq = 0.0f, iv = 0.0f;
     if (r < n_rows) {
         b = row_norms[r];
-        bsq = (b * b) * (1.0f - gamma);
+        if (inv)
+            iv = 1.0f / (i8_scale * b);
+        if (norm_in_mfma_range(b) && (!inv || norm_in_mfma_range(fabsf(iv)))) {
+            bsq = (b * b) * (1.0f - gamma);
+        } else {
+            iv = 0.0f;
+            atomicOr(&stats[0], 1u);
+            b = 0.0f;
+        }
     }
     out[r] = make_float2(b, bsq);
+    if (inv)
+        inv[r] = iv;
 }
 
 // ---- query prep: one wave per query -------------------------------------------------------
@@ -215,6 +229,59 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
     }
 }
 
+// ---- query prep, int8 stores: one wave per query -------------------------------------------------------
+// q^ = q / a is quantized to int8 with its own scale: s_q = max |q^_j| / 127, q~_j = round(q^_j / s_q).  The mirror
+// row is int8 in the fragment order of v_mfma_i32_32x32x32_i8 (unit = 32 queries x 32 k, lane l: query l & 31,
+// 16 consecutive k from 16 (l >> 5)), zero beyond dim.  The rows are exact integers, so the whole score error is the
+// query's: |s_q S / ||b|| - cos| <= r_q = || q^ - s_q q~ ||_2 (Cauchy-Schwarz), measured here with its own f32
+// roundings added; eps_q = r_q (1 + 2^-7) + f32 slack as on the bf16 path.
+__global__ void mfma_query_prep_i8_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
+                                          int8_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad,
+                                          float *__restrict__ q_norm, float *__restrict__ q_eps,
+                                          float *__restrict__ q_scale, float f32_slack)
+{
+    const uint32_t q = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const float *src = q_in + (size_t)q * dim;
+    float s = 0.0f, mx = 0.0f;
+    for (uint32_t j = lane; j < dim; j += 64) {
+        s += src[j] * src[j];
+        mx = fmaxf(mx, fabsf(src[j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    const float n1 = __builtin_sqrtf(s);
+    const bool ok = norm_in_mfma_range(n1) && mx > 0.0f;
+    const float sq = ok ? (mx / n1) / 127.0f : 0.0f; // the largest component maps to +-127 (up to rounding: clamped)
+    float res = 0.0f;
+    if (ok) {
+        for (uint32_t k = lane; k < dim; k += 64) {
+            const float y = src[k] / n1;
+            float t = rintf(y / sq);
+            t = fminf(fmaxf(t, -127.0f), 127.0f);
+            const uint32_t unit = (q >> 5) * KS + (k >> 5);
+            const uint32_t l2 = (q & 31u) + 32u * ((k & 31u) >> 4);
+            q_mirror[((size_t)unit * 64u + l2) * 16u + (k & 15u)] = (int8_t)(int)t;
+            const float d = y - sq * t; // two roundings of <= 2^-24 |y| each: covered below
+            res += d * d;
+        }
+    } // else: the mirror row stays zero (memset by the host) and the query takes the exact scan
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        res += __shfl_xor(res, o, 64);
+    if (lane == 0) {
+        q_bad[q] = ok ? 0 : 1;
+        q_norm[q] = ok ? n1 : 0.0f;
+        q_scale[q] = sq;
+        // + 2^-22: the f32 roundings inside d (<= 3 * 2^-24 ||q^||) and of q^ itself
+        const float r_q = residual_norm_bound(res, KS * 32u) + 0x1p-22f;
+        q_eps[q] = r_q * (1.0f + 0x1p-7f) + f32_slack;
+    }
+}
+
 // ---- prefilter GEMM ---------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 frag_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -227,6 +294,18 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
     } c;
     c.u = v;
     return c.b;
+}
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// one 32 x 32 MFMA on a 16-byte fragment pair: 16 bf16 k (f32 accumulators) or 32 int8 k (exact i32 accumulators)
+__device__ __forceinline__ f32x16 mfma_32x32(uint4 a, uint4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+}
+__device__ __forceinline__ i32x16 mfma_32x32(uint4 a, uint4 b, i32x16 c)
+{
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
 }
 
 // ---- prefilter GEMM, 256 rows x 256 queries per workgroup ------------------------------------------
@@ -255,7 +334,17 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v)
 // divided by, eps_q >= |s~ - q.x / (a b)| per query (q_eps, written by mfma_query_prep_kernel), gamma
 // covering the f32 error of b^2 vs ||x||^2; the three roundings here are covered by the surplus f32 slack
 // inside eps_q (error model at the end of the file).  rn2[row] = (b, b^2 (1 - gamma)).
-template <int KU, int NSTAGE, int MODE>
+//
+// I8 (int8 stores): the same kernel on v_mfma_i32_32x32x32_i8 -- twice the k per instruction at the same cycles --
+// with NO mirror of the corpus at all.  A 16-byte rb64 chunk is 16 consecutive k of one row, which is exactly one
+// lane's share of that MFMA's A operand (lane l: row l & 31, k-half l >> 5), so the stage reads the rb64 corpus
+// itself: per-lane source offset (l >> 5) * 1024 + (l & 31) * 16 inside a (row-block, chunk pair), everything else
+// in SGPRs as before.  The query operand is int8 in the same fragment order (mfma_query_prep_i8_kernel), ZERO
+// beyond dim: K is padded to the ring round (256) by reading whatever follows the row's last chunk (the next
+// row-block, or 0 past the allocation: the buffer resource is bounded) times a zero query byte.  The dot product
+// S = sum b_j q~_j is exact in int32; the score is S / (scale ||x||), one v_cvt and one multiply in the epilogue
+// (Euclidean: two FMAs on the same per-row / per-query constants as the bf16 epilogue).
+template <int KU, int NSTAGE, int MODE, bool I8>
 __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__restrict__ A,
                                                                 const uint4 *__restrict__ B,
                                                                 float *__restrict__ cand, uint32_t n_rows,
@@ -263,7 +352,10 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                                                                 uint32_t nq, uint32_t n_lists, uint32_t strip_tiles,
                                                                 const float2 *__restrict__ rn2,
                                                                 const float *__restrict__ q_norm,
-                                                                const float *__restrict__ q_eps)
+                                                                const float *__restrict__ q_eps,
+                                                                uint32_t a_chunks, uint64_t a_bytes,
+                                                                const float *__restrict__ inv_rn,
+                                                                const float *__restrict__ q_scale, float i8_scale)
 {
     constexpr uint32_t TROWS = 256u, TQ = 256u;
     constexpr uint32_t A_UNITS = 8u * KU, UNITS = 16u * KU;
@@ -309,7 +401,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     // per-piece 64-bit vector address arithmetic.  Pieces are issued two per 8-MFMA group (see kstep)
     // instead of as a burst behind the barrier.
     const bool a_wave = wave < 4u;
-    const uint32_t lane16 = lane * 16u;
+    const bool rb64_src = I8 && a_wave; // this wave stages straight out of the rb64 corpus
+    const uint32_t lane16 = rb64_src ? (lane >> 5) * 1024u + (lane & 31u) * 16u : lane * 16u;
     // All bookkeeping below is wave-uniform and incremental (SGPRs, a handful of s_add per K-step):
     // per-piece constants, the next stage's K offset and tile base, the current K-step's position.
     uint32_t pc_soff[G], pc_lds[G];
@@ -317,20 +410,32 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     for (uint32_t u = 0; u < G; ++u) {
         const uint32_t unit = (wave & 3u) * G + u; // 0 .. 8 KU - 1
         const uint32_t grp = unit / KU, ks = unit % KU;
-        pc_soff[u] = (grp * KS + ks) * 1024u;
+        // rb64: 32-row group grp = row-block grp >> 1 of the tile, its rows 32 (grp & 1) ..; k-slice ks = chunk pair
+        pc_soff[u] = rb64_src ? (grp >> 1) * a_chunks * 1024u + (grp & 1u) * 512u + ks * 2048u : (grp * KS + ks) * 1024u;
         pc_lds[u] = ((a_wave ? 0u : A_UNITS) + unit) * 1024u;
     }
-    const uint32_t tile_bytes = 8u * KS * 1024u; // one 256-row tile of the mirror
-    uintptr_t nx_base = a_wave ? (uintptr_t)A + (uintptr_t)tile0 * tile_bytes : (uintptr_t)B + (uintptr_t)qtile * tile_bytes;
+    const uint32_t q_tile_bytes = 8u * KS * 1024u; // one 256-query tile of the query mirror
+    const uint32_t tile_bytes = rb64_src ? 4u * a_chunks * 1024u : q_tile_bytes; // one 256-row tile of the rows
+    const uint32_t koff_step = rb64_src ? KU * 2048u : KU * 1024u;               // one K-step inside a row / unit row
+    const uint32_t koff_end = koff_step * (KS / KU);
+    uintptr_t nx_base = a_wave ? (uintptr_t)A + (uintptr_t)tile0 * tile_bytes : (uintptr_t)B + (uintptr_t)qtile * q_tile_bytes;
+    const uintptr_t a_end = (uintptr_t)A + a_bytes;
     uint32_t nx_idx = 0, nx_koff = 0; // next stage to issue: index, byte offset of its K-slice inside a unit row
     auto next_rsrc = [&]() -> __amdgpu_buffer_rsrc_t {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, 0xffffffff, 0x00020000);
+        // rb64 source: bounded by the corpus allocation (the K padding and the last tile's missing row-blocks
+        // read past it and must get zeros, not a fault)
+        uint32_t bound = 0xffffffffu;
+        if (rb64_src) {
+            const uintptr_t left = nx_base < a_end ? a_end - nx_base : 0;
+            bound = left < 0xffffffffu ? (uint32_t)left : 0xffffffffu;
+        }
+        return __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, bound, 0x00020000);
     };
     auto advance = [&]() { // past the last stage: stay (the redundant re-issue keeps the vmcnt arithmetic constant)
         if (nx_idx + 1u < n_it) {
             ++nx_idx;
-            nx_koff += KU * 1024u;
-            if (nx_koff == KS * 1024u) {
+            nx_koff += koff_step;
+            if (nx_koff == koff_end) {
                 nx_koff = 0;
                 if (a_wave)
                     nx_base += tile_bytes;
@@ -355,26 +460,30 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         advance();
     };
 
-    f32x16 acc[4][2];
+    typename std::conditional<I8, i32x16, f32x16>::type acc[4][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                acc[mi][ni][r] = 0.0f;
+                acc[mi][ni][r] = 0;
     const float ninf = __uint_as_float(0xff800000u);
     float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
     uint32_t keep_mask = ~kIdxMask;
     asm volatile("" : "+v"(keep_mask)); // keep it in a VGPR (see the epilogue)
     uint32_t cur_kt = 0, cur_ts = 0;    // position of the running K-step inside the strip
-    float cq[2] = {0.0f, 0.0f}, ce[2] = {0.0f, 0.0f}; // MODE 1: 2a and eps_q per query column
+    // MODE 1, per query column: bf16: cq = 2a, ce = eps_q;  int8: cq = 2a s_q / scale (times S), ce = 2a eps_q (times ||x||)
+    float cq[2] = {0.0f, 0.0f}, ce[2] = {0.0f, 0.0f};
     if (MODE == 1) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
-            cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
-            ce[ni] = q < nq ? q_eps[q] : 0.0f;
+            if (q < nq) {
+                const float a2 = 2.0f * q_norm[q];
+                cq[ni] = I8 ? a2 * q_scale[q] / i8_scale : a2;
+                ce[ni] = I8 ? a2 * q_eps[q] : q_eps[q];
+            }
         }
     }
 
@@ -392,6 +501,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                     const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
                     bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
                     bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
+                } else if (I8) { // 1 / (scale ||x||) of the 4 rows (padded to the tile, 0 beyond n_rows)
+                    const float4 p = *(const float4 *)(inv_rn + row4);
+                    bn[0] = p.x, bn[1] = p.y, bn[2] = p.z, bn[3] = p.w;
                 }
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
@@ -402,8 +514,12 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r));
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
-                        float v = acc[mi][ni][r];
-                        if (MODE == 1)
+                        float v = (float)acc[mi][ni][r];
+                        if (I8 && MODE == 1) // upper bound of V = 2 q.x - ||x||^2: 2a (s_q S / scale + eps_q ||x||) - ||x||^2 (1 - gamma)
+                            v = __builtin_fmaf(v, cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
+                        else if (I8) // S / (scale ||x||): the cosine up to the query's scale s_q (mfma_rescore_kernel applies it)
+                            v = v * bn[rl];
+                        else if (MODE == 1)
                             v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
                         float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
                         if (RAGGED && row4 + (uint32_t)rl >= n_rows)
@@ -413,7 +529,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                         m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
                         m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
                         asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
-                        acc[mi][ni][r] = 0.0f;
+                        acc[mi][ni][r] = 0;
                     }
                 }
             }
@@ -442,13 +558,13 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         advance();
 #pragma unroll
         for (uint32_t ks = 0; ks < (uint32_t)KU; ++ks) {
-            bf16x8 a[4], b[2];
+            uint4 a[4], b[2];
 #pragma unroll
             for (uint32_t mi = 0; mi < 4; ++mi)
-                a[mi] = as_bf16x8(rd[((wave_m * 4u + mi) * KU + ks) * 64u + lane]);
+                a[mi] = rd[((wave_m * 4u + mi) * KU + ks) * 64u + lane];
 #pragma unroll
             for (uint32_t ni = 0; ni < 2; ++ni)
-                b[ni] = as_bf16x8(rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane]);
+                b[ni] = rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane];
             // next stage's pieces: spread over the K-step when the ring gives them NSTAGE-1 >= 2 K-steps
             // to land, front-loaded (first half of the K-step) when the very next barrier needs them
             constexpr uint32_t PPK = NSTAGE > 2 ? 2u : 4u;
@@ -461,7 +577,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mfma_32x32(a[mi], b[ni], acc[mi][ni]);
         }
         if (++cur_kt == KT) {
             // tile finished: fold its 128 scores per lane into the running top-3 of each query column.
@@ -819,7 +935,8 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, const float *__restrict__ q_eps, uint64_t row_base,
-    uint64_t id_base, uint32_t strip_tiles, const float *__restrict__ q_norm, float gamma, int only_flagged)
+    uint64_t id_base, uint32_t strip_tiles, const float *__restrict__ q_norm, float gamma, int only_flagged,
+    const float *__restrict__ q_scale)
 {
     if (only_flagged && flags[blockIdx.x] == 0) // second, wider pass: flagged queries only (uniform exit)
         return;
@@ -957,8 +1074,9 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
         const double sc = (double)score;
         above = valid && (sc + 0x1p-12 * (sc < 0.0 ? -sc : sc) >= vk_low);
     } else {
+        // int8 stores: the candidate score is S / (scale ||x||); the query's scale s_q makes it the cosine estimate
         const float thr = (1.0f - dk) - (q_eps[q] + 0x1p-13f);
-        above = valid && score >= thr;
+        above = valid && (q_scale ? q_scale[q] * score : score) >= thr;
     }
     // (1) rows listed but not selected score <= the worst selected one (sel is sorted, full => index kp-1)
     if (ci == kp - 1u && valid && above)
@@ -1020,10 +1138,18 @@ hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t 
 }
 
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
-                                     hipStream_t s)
+                                     float *inv, float i8_scale, uint32_t *stats, hipStream_t s)
 {
     hipLaunchKernelGGL(mfma_rownorm_pairs_kernel, dim3((n_pad + 255u) / 256u), dim3(256), 0, s, row_norms, n_rows,
-                       n_pad, gamma, (float2 *)out);
+                       n_pad, gamma, (float2 *)out, inv, i8_scale, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
+                                     int *q_bad, float *q_norm, float *q_eps, float *q_scale, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_query_prep_i8_kernel, dim3(nq), dim3(64), 0, s, d_queries, nq, dim, (int8_t *)q_mirror, KS,
+                       q_bad, q_norm, q_eps, q_scale, mfma_f32_slack(KS * 32u));
     return hipGetLastError();
 }
 
@@ -1057,8 +1183,30 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
         return hipGetLastError();
     }
 #define VFSX_PF256(MODE)                                                                                           \
-    hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2, MODE>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,     \
-                       g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps)
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2, MODE, false>), grid, dim3(512), 0, s, mirror, qm, cand,      \
+                       n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps, 0u,   \
+                       (uint64_t)0, (const float *)nullptr, (const float *)nullptr, 1.0f)
+    if (euclid)
+        VFSX_PF256(1);
+    else
+        VFSX_PF256(0);
+#undef VFSX_PF256
+    return hipGetLastError();
+}
+
+// int8 stores: `corpus` is the rb64 corpus itself (d_chunks chunks per row, corpus_bytes allocated), q_mirror the
+// int8 query mirror; g from mfma_geometry(..., true)
+hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint64_t corpus_bytes, const void *q_mirror,
+                                    float *cand, uint32_t n_rows, const MfmaGeometry &g, uint32_t nq, int euclid,
+                                    const float *rn2, const float *inv_rn, const float *q_norm, const float *q_eps,
+                                    const float *q_scale, float i8_scale, hipStream_t s)
+{
+    const uint32_t n_qtiles = (nq + 255u) / 256u;
+    const dim3 grid(g.n_strips * n_qtiles);
+#define VFSX_PF256(MODE)                                                                                           \
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2, MODE, true>), grid, dim3(512), 0, s, corpus,                 \
+                       (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,          \
+                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale, i8_scale)
     if (euclid)
         VFSX_PF256(1);
     else
@@ -1093,7 +1241,7 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,           \
                        a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks,    \
                        a.q_stride, a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma,       \
-                       a.only_flagged)
+                       a.only_flagged, a.q_scale)
     if (dtype == VFSX_I8) {
         if (a.euclid)
             VFSX_RESCORE(VFSX_I8, VFSX_EUCLIDEAN);
@@ -1109,12 +1257,13 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     return hipGetLastError();
 }
 
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim)
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8)
 {
     MfmaGeometry g;
-    // whole ring rounds only: K-steps (of 64) per tile % ring depth (2) == 0 <=> K % 128 == 0
-    g.k_pad = (dim + 127u) / 128u * 128u;
-    g.KS = g.k_pad / 16u;
+    // whole ring rounds only: K-steps (of 4 MFMA k-slices: 64 bf16 / 128 int8 k) per tile % ring depth (2) == 0
+    const uint32_t k_round = int8 ? 256u : 128u;
+    g.k_pad = (dim + k_round - 1u) / k_round * k_round;
+    g.KS = g.k_pad / (int8 ? 32u : 16u);
     g.n_rowtiles = (n_rows + 255u) / 256u;
     // aim for >= ~4096 candidate lists per query so that three rows above the safety margin rarely share
     // one (small corpora get short strips -- and more workgroups); a list holds at most 1024 rows (10 index
@@ -1122,7 +1271,7 @@ MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim)
     g.strip_tiles = std::min<uint32_t>(kMaxStripTiles, std::max<uint32_t>(1u, (n_rows / 256u) * 4u / 4096u));
     g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
     g.n_lists = g.n_strips * 4u;
-    g.mirror_bytes = (size_t)g.n_rowtiles * 256u * g.k_pad * 2u;
+    g.mirror_bytes = int8 ? 0 : (size_t)g.n_rowtiles * 256u * g.k_pad * 2u; // int8 stores need no mirror
     return g;
 }
 
