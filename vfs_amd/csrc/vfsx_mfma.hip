@@ -344,6 +344,18 @@ __device__ __forceinline__ i32x16 mfma_32x32(uint4 a, uint4 b, i32x16 c)
 // row-block, or 0 past the allocation: the buffer resource is bounded) times a zero query byte.  The dot product
 // S = sum b_j q~_j is exact in int32; the score is S / (scale ||x||), one v_cvt and one multiply in the epilogue
 // (Euclidean: two FMAs on the same per-row / per-query constants as the bf16 epilogue).
+#ifndef VFSX_PF_KU // K-step (in 16-byte fragment k-slices) and ring depth of mfma_prefilter256_kernel
+#define VFSX_PF_KU 4
+#define VFSX_PF_NSTAGE 2
+#endif
+
+#ifdef VFSX_EXP_STAMPS // diagnostic build only: where a wave's cycles go inside a K-step (s_memtime sums over all waves)
+__device__ unsigned long long exp_stamps[8];
+#define VFSX_STAMP(x) const uint64_t x = __builtin_amdgcn_s_memtime()
+#else
+#define VFSX_STAMP(x)
+#endif
+
 template <int KU, int NSTAGE, int MODE, bool I8>
 __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__restrict__ A,
                                                                 const uint4 *__restrict__ B,
@@ -355,7 +367,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                                                                 const float *__restrict__ q_eps,
                                                                 uint32_t a_chunks, uint64_t a_bytes,
                                                                 const float *__restrict__ inv_rn,
-                                                                const float *__restrict__ q_scale, float i8_scale)
+                                                                const float *__restrict__ q_scale, float i8_scale,
+                                                                uint32_t qpx, uint32_t n_strips)
 {
     constexpr uint32_t TROWS = 256u, TQ = 256u;
     constexpr uint32_t A_UNITS = 8u * KU, UNITS = 16u * KU;
@@ -372,24 +385,18 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
     const uint32_t wave_m = wave >> 2, wave_n = wave & 3u;
 
-    // XCD-aware mapping (speed only).  Workgroups with equal id % 8 share an XCD and its 4 MiB L2.
-    // Give each XCD a fixed slice of the query tiles (its share of Q~ then stays L2-resident) and let
-    // it walk the row strips in order; all XCDs walk the strips at the same pace, so a strip fetched
-    // by one XCD is served to the others from the Infinity Cache.  Needs n_qtiles % 8 == 0;
-    // otherwise fall back to consecutive tiles per XCD (bijective remap).
-    const uint32_t total = gridDim.x;
-    const uint32_t id = blockIdx.x, xcd = id & 7u;
-    uint32_t strip, qtile;
-    if ((n_qtiles & 7u) == 0u) {
-        const uint32_t qpx = n_qtiles >> 3, within = id >> 3;
-        strip = within / qpx;
-        qtile = xcd * qpx + within % qpx;
-    } else {
-        const uint32_t q8 = total >> 3, r8 = total & 7u;
-        const uint32_t t = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
-        strip = t / n_qtiles;
-        qtile = t % n_qtiles;
-    }
+    // XCD-aware mapping (speed only).  Workgroups with equal id % 8 share an XCD and its 4 MiB L2.  The query tiles
+    // are cut into G groups of qpx (G divides 8); XCD x works on group x % G -- its qpx tiles of Q~ stay L2-resident
+    // -- and on every (8 / G)-th row strip, qpx workgroups per strip side by side: a row tile is fetched into the
+    // XCD's L2 once and served from there to the other qpx - 1, and the XCDs that need the same strip walk the strips
+    // at the same pace, so that one HBM read serves them through the Infinity Cache.  The host picks qpx (pf_grid)
+    // and sizes the grid to 8 * qpx * ceil(n_strips / (8 / G)); surplus workgroups leave here, as a whole.
+    const uint32_t id = blockIdx.x, xcd = id & 7u, within = id >> 3;
+    const uint32_t n_groups = n_qtiles / qpx, lanes = 8u / n_groups;
+    const uint32_t qtile = (xcd % n_groups) * qpx + within % qpx;
+    const uint32_t strip = (within / qpx) * lanes + xcd / n_groups;
+    if (strip >= n_strips)
+        return;
     const uint32_t tile0 = strip * strip_tiles;
     const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
     const uint32_t KT = KS / KU;
@@ -514,6 +521,12 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | ((uint32_t)mi << 4) | (uint32_t)r));
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
+#ifdef VFSX_EXP_NOFOLD // experiment (wrong results): what the kernel costs without its epilogue
+                        if (r != 0) {
+                            acc[mi][ni][r] = 0;
+                            continue;
+                        }
+#endif
                         float v = (float)acc[mi][ni][r];
                         if (I8 && MODE == 1) // upper bound of V = 2 q.x - ||x||^2: 2a (s_q S / scale + eps_q ||x||) - ||x||^2 (1 - gamma)
                             v = __builtin_fmaf(v, cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
@@ -535,50 +548,82 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             }
     };
 
+#ifdef VFSX_EXP_STAMPS
+    uint64_t st_vm = 0, st_bar = 0, st_body = 0, st_fold = 0, st_n = 0;
+    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+#endif
+    // Fragment registers: two sets, k-slice ks uses set ks & 1 (KU is even, so every K-step starts on set 0).
+    // PREFETCH (NSTAGE >= 3): the fragments of k-slice ks + 1 are read while the MFMAs of k-slice ks run, ACROSS the
+    // barrier too -- the last k-slice of K-step `it` reads the first fragments of K-step it + 1.  That needs stage
+    // it + 1 complete and visible one barrier early, so barrier(it) waits for the stages up to it + 1 (all but the
+    // youngest NSTAGE - 3 in flight), which a ring of >= 3 slots affords.  Without it every barrier is followed by a
+    // bubble in which all 8 waves wait for their first ds_reads (48 KiB through the LDS at once) and no MFMA issues:
+    // stamped at ~250-300 cycles per barrier (profiles/r02/c4_analysis.md).
+    constexpr bool PREFETCH = NSTAGE >= 3;
+    static_assert(KU % 2 == 0, "fragment sets alternate per k-slice");
+    uint4 fa[2][4], fb[2][2];
+    auto load_frags = [&](const uint4 *rd, uint32_t ks, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t mi = 0; mi < 4; ++mi)
+            fa[set][mi] = rd[((wave_m * 4u + mi) * KU + ks) * 64u + lane];
+#pragma unroll
+        for (uint32_t ni = 0; ni < 2; ++ni)
+            fb[set][ni] = rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane];
+    };
     auto kstep = [&](auto jc, uint32_t it) {
         constexpr int J = decltype(jc)::value;
         constexpr int JW = (J + NSTAGE - 1) % NSTAGE;
+        constexpr int JN = (J + 1) % NSTAGE;
         const uint4 *rd = slot(J);
         // Every K-step issues exactly one stage (past the end: a redundant copy of the last one into
-        // the free slot), so NSTAGE-2 younger stages are always in flight here and the count is a
-        // constant.  It also keeps hipcc's own (path-insensitive) LDS-DMA bookkeeping off vmcnt(0):
-        // with conditional stages it must assume none was issued and drains the ring once per
-        // unrolled round.
-        if (G * (NSTAGE - 2) == 4)
+        // the free slot), so the number of younger stages in flight here is a constant.  It also keeps
+        // hipcc's own (path-insensitive) LDS-DMA bookkeeping off vmcnt(0): with conditional stages it must
+        // assume none was issued and drains the ring once per unrolled round.
+        constexpr uint32_t IN_FLIGHT = G * (PREFETCH ? NSTAGE - 3 : NSTAGE - 2);
+        VFSX_STAMP(t0);
+        if (IN_FLIGHT == 4)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (G * (NSTAGE - 2) == 8)
+        else if (IN_FLIGHT == 8)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VFSX_STAMP(t1);
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory"); // no fragment read may be hoisted above the barrier
+        asm volatile("" ::: "memory"); // no fragment read of this stage (PREFETCH: the next) may be hoisted above
+        VFSX_STAMP(t2);
         const __amdgpu_buffer_rsrc_t rsrc_n = next_rsrc();
         const uint32_t koff_n = nx_koff;
         const uint32_t wr = lds_addr(slot(JW));
         advance();
 #pragma unroll
         for (uint32_t ks = 0; ks < (uint32_t)KU; ++ks) {
-            uint4 a[4], b[2];
-#pragma unroll
-            for (uint32_t mi = 0; mi < 4; ++mi)
-                a[mi] = rd[((wave_m * 4u + mi) * KU + ks) * 64u + lane];
-#pragma unroll
-            for (uint32_t ni = 0; ni < 2; ++ni)
-                b[ni] = rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane];
+            const int set = (int)(ks & 1u);
+            if (!PREFETCH)
+                load_frags(rd, ks, set);
+            else if (ks + 1u < (uint32_t)KU)
+                load_frags(rd, ks + 1u, set ^ 1);
+            else
+                load_frags(slot(JN), 0u, set ^ 1);
             // next stage's pieces: spread over the K-step when the ring gives them NSTAGE-1 >= 2 K-steps
-            // to land, front-loaded (first half of the K-step) when the very next barrier needs them
-            constexpr uint32_t PPK = NSTAGE > 2 ? 2u : 4u;
+            // to land, front-loaded (first half of the K-step) when the very next barrier needs them: any later
+            // piece of a 2-slot ring lands late (3,3,2,0 / 2,2,2,2 per k-slice: +4..5 %, measured)
+            constexpr uint32_t PPK = NSTAGE > 2 ? (G + KU - 1u) / KU : 4u;
             if (ks * PPK < G) {
 #pragma unroll
                 for (uint32_t u = 0; u < PPK; ++u)
-                    stage_piece(rsrc_n, koff_n, wr, ks * PPK + u);
+                    if (ks * PPK + u < G)
+                        stage_piece(rsrc_n, koff_n, wr, ks * PPK + u);
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = mfma_32x32(a[mi], b[ni], acc[mi][ni]);
+                    acc[mi][ni] = mfma_32x32(fa[set][mi], fb[set][ni], acc[mi][ni]);
         }
+        VFSX_STAMP(t3);
+#ifdef VFSX_EXP_STAMPS
+        st_vm += t1 - t0, st_bar += t2 - t1, st_body += t3 - t2, st_n += 1;
+#endif
         if (++cur_kt == KT) {
             // tile finished: fold its 128 scores per lane into the running top-3 of each query column.
             // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
@@ -590,6 +635,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                 fold_tile(std::true_type{}, ts, tile_row0); // last, ragged tile: rows >= n_rows masked
             else
                 fold_tile(std::false_type{}, ts, tile_row0);
+#ifdef VFSX_EXP_STAMPS
+            st_fold += __builtin_amdgcn_s_memtime() - t3;
+#endif
         }
     };
 
@@ -598,6 +646,17 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         stage(lds_s1);
     if (NSTAGE > 3)
         stage(lds_s2);
+    if (PREFETCH) { // stage 0 landed everywhere -> the first fragments of K-step 0
+        if (G * (NSTAGE - 2) == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (G * (NSTAGE - 2) == 8)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_frags(lds_s0, 0u, 0);
+    }
     // n_it % NSTAGE == 0 (the host pads K so that KT is a multiple of NSTAGE): a straight-line round
     for (uint32_t it = 0; it < n_it; it += NSTAGE) {
         kstep(std::integral_constant<int, 0>{}, it);
@@ -610,6 +669,17 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 
     // the redundant tail stages are still in flight: they must land before this workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VFSX_EXP_STAMPS
+    if (lane == 0) {
+        atomicAdd(&exp_stamps[0], (unsigned long long)st_vm);
+        atomicAdd(&exp_stamps[1], (unsigned long long)st_bar);
+        atomicAdd(&exp_stamps[2], (unsigned long long)st_body);
+        atomicAdd(&exp_stamps[3], (unsigned long long)st_fold);
+        atomicAdd(&exp_stamps[4], (unsigned long long)st_n);
+        atomicAdd(&exp_stamps[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st_begin));
+        atomicAdd(&exp_stamps[6], 1ull);
+    }
+#endif
 
     const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
 #pragma unroll
@@ -1137,6 +1207,21 @@ hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t 
     return hipGetLastError();
 }
 
+#ifdef VFSX_EXP_STAMPS
+} // namespace vfsx
+extern "C" int vfsx_exp_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vfsx::exp_stamps), sizeof(unsigned long long) * 8) != hipSuccess)
+        return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(vfsx::exp_stamps), z, sizeof(z)) != hipSuccess;
+    }
+    return 0;
+}
+namespace vfsx {
+#endif
+
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
                                      float *inv, float i8_scale, uint32_t *stats, hipStream_t s)
 {
@@ -1154,12 +1239,33 @@ hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32
 }
 
 // euclid != 0: Euclidean upper-bound epilogue; rn2 / q_norm / q_eps as in the kernel
+// Grid of mfma_prefilter256_kernel and its query tiles per XCD (see the kernel's mapping comment): the most query
+// tiles whose share of Q~ fits half an XCD's L2 (4 MiB) among the groupings the mapping allows, or VFSX_MFMA_QPX.
+static dim3 pf_grid(const MfmaGeometry &g, uint32_t n_qtiles, size_t qtile_bytes, uint32_t *qpx_out)
+{
+    static const uint32_t forced = std::getenv("VFSX_MFMA_QPX") ? (uint32_t)std::atoi(std::getenv("VFSX_MFMA_QPX")) : 0u;
+    uint32_t qpx = 0;
+    for (uint32_t groups = 8u; groups >= 1u; groups >>= 1) { // ascending qpx
+        if (n_qtiles % groups)
+            continue;
+        const uint32_t cand = n_qtiles / groups;
+        if (qpx == 0 || cand == forced || (forced == 0 && (size_t)cand * qtile_bytes <= (2u << 20)))
+            qpx = cand;
+        if (cand == forced)
+            break;
+    }
+    const uint32_t lanes = 8u / (n_qtiles / qpx);
+    *qpx_out = qpx;
+    return dim3(8u * qpx * ((g.n_strips + lanes - 1u) / lanes));
+}
+
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
                                  const float *q_norm, const float *q_eps, hipStream_t s)
 {
     const uint32_t n_qtiles = (nq + 255u) / 256u;
-    const dim3 grid(g.n_strips * n_qtiles);
+    uint32_t qpx = 1;
+    const dim3 grid = pf_grid(g, n_qtiles, (size_t)256u * g.k_pad * 2u, &qpx);
     const uint4 *qm = (const uint4 *)q_mirror;
     const float2 *rn = (const float2 *)rn2;
     // <= 128 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
@@ -1183,9 +1289,10 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
         return hipGetLastError();
     }
 #define VFSX_PF256(MODE)                                                                                           \
-    hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2, MODE, false>), grid, dim3(512), 0, s, mirror, qm, cand,      \
-                       n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps, 0u,   \
-                       (uint64_t)0, (const float *)nullptr, (const float *)nullptr, 1.0f)
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, false>), grid, dim3(512), 0, s,  \
+                       mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn,    \
+                       q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr, (const float *)nullptr, 1.0f, qpx,   \
+                       g.n_strips)
     if (euclid)
         VFSX_PF256(1);
     else
@@ -1202,11 +1309,13 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
                                     const float *q_scale, float i8_scale, hipStream_t s)
 {
     const uint32_t n_qtiles = (nq + 255u) / 256u;
-    const dim3 grid(g.n_strips * n_qtiles);
+    uint32_t qpx = 1;
+    const dim3 grid = pf_grid(g, n_qtiles, (size_t)256u * g.k_pad, &qpx);
 #define VFSX_PF256(MODE)                                                                                           \
-    hipLaunchKernelGGL((mfma_prefilter256_kernel<4, 2, MODE, true>), grid, dim3(512), 0, s, corpus,                 \
-                       (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,          \
-                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale, i8_scale)
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, true>), grid, dim3(512), 0, s,   \
+                       corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,  \
+                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale,  \
+                       i8_scale, qpx, g.n_strips)
     if (euclid)
         VFSX_PF256(1);
     else
