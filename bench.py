@@ -122,8 +122,8 @@ def main(argv=None) -> int:
     mfma = workload in MFMA_WORKLOADS
     if mfma:
         args.mode = "batch"
-        if args.steps == 40:
-            args.steps, args.warmup = 5, 1
+        if args.steps == 40:  # ~2 s of timed region at 40-70 ms per 4096-query batch
+            args.steps, args.warmup = 30, 2
     if args.rows:
         rows = args.rows
     if args.dim:

@@ -59,8 +59,10 @@ dom = bench["roofline"]["kernel"]
 scan = [k for k in out["kernels"] if dom in k["name"]][0]
 if bench["roofline"]["bound"] == "mfma":
     flops = bench["roofline"]["algorithmic_flops_per_launch"]
+    peak, unit = bench["roofline"]["peak"], bench["roofline"]["unit"]
     md += ["", f"Dominant kernel: {dom}. Algorithmic flops/launch {flops:.4g}; avg duration {scan['avg_ns']/1e6:.2f} ms -> "
-           f"{flops/scan['avg_ns']/1e3:.1f} TFLOP/s = {flops/scan['avg_ns']/1e3/2500*100:.1f}% of the 2.5 PF dense bf16 MFMA peak; "
+           f"{flops/scan['avg_ns']/1e3:.1f} {unit} = {flops/scan['avg_ns']/1e3/peak*100:.1f}% of the {peak/1000:g} P{unit[1:]} dense MFMA peak "
+           f"for this operand type; "
            f"HBM bytes/launch {scan['hbm_bytes']} (mirror + query re-reads that miss L2/MALL).",
            "", "bench.py line from the same (profiled) run:", "", "```", bench_line.strip(), "```"]
 else:

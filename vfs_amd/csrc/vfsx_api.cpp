@@ -184,7 +184,7 @@ struct vfsx_corpus {
     DeviceBuf<float> fb_queries;
     DeviceBuf<vfsx_hit> fb_hits;
     bool mirror_bad = false;
-    uint32_t mfma_min_batch = 8;
+    uint32_t mfma_min_batch = 4;
     uint32_t mfma_kp_override = 0; // VFSX_MFMA_KP: first-pass candidates per query (0 = by k)
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
@@ -999,7 +999,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
         c->n_cus = (uint32_t)prop.multiProcessorCount;
         c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
-        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", dtype == VFSX_I8 ? 8 : 4); // measured crossover
+        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 4); // measured crossover (profiles/r02/batch_crossover.txt)
         c->mfma_kp_override = (uint32_t)env_u64("VFSX_MFMA_KP", 0);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));

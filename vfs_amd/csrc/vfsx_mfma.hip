@@ -701,7 +701,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 // kernel runs at the mirror's HBM rate.  Output: the candidate lists of mfma_prefilter256_kernel, bit for bit
 // the same format (wave w covers what (wave_m, mi) = (w >> 2, w & 3) covers there; the four waves of one
 // wave_m merge their top-3 through LDS at the end), so select / re-score are shared.
-template <int NSTAGE, int MODE, int NCOL>
+// I8: as in mfma_prefilter256_kernel -- the row pieces come straight out of the rb64 corpus (a_chunks chunks per
+// row, a_bytes allocated), the MFMA is v_mfma_i32_32x32x32_i8, the score S / (scale ||x||).
+template <int NSTAGE, int MODE, int NCOL, bool I8>
 __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 *__restrict__ A,
                                                                     const uint4 *__restrict__ B,
                                                                     float *__restrict__ cand, uint32_t n_rows,
@@ -709,7 +711,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                                                                     uint32_t n_lists, uint32_t strip_tiles,
                                                                     const float2 *__restrict__ rn2,
                                                                     const float *__restrict__ q_norm,
-                                                                    const float *__restrict__ q_eps)
+                                                                    const float *__restrict__ q_eps, uint32_t a_chunks,
+                                                                    uint64_t a_bytes, const float *__restrict__ inv_rn,
+                                                                    const float *__restrict__ q_scale, float i8_scale)
 {
     constexpr uint32_t KU = 4u, TROWS = 256u;
     // NCOL = 64-query columns per workgroup (1: <= 64 queries, 2: <= 128): 32 row units + 8 NCOL query units of
@@ -730,23 +734,34 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
 
     // staging: every wave moves 4 row pieces (its own 32-row group, the 4 k-slices) and 1 query piece per stage
     const uint32_t lane16 = lane * 16u;
-    const uint32_t tile_bytes = 8u * KS * 1024u; // one 256-row tile of the mirror
-    const uint32_t a_soff = wave * KS * 1024u, a_lds = wave * KU * 1024u;
+    // rb64 source (I8): 32-row group `wave` = row-block wave >> 1, rows 32 (wave & 1) ..; k-slice = a chunk pair
+    const uint32_t lane16a = I8 ? (lane >> 5) * 1024u + (lane & 31u) * 16u : lane16;
+    const uint32_t tile_bytes = I8 ? 4u * a_chunks * 1024u : 8u * KS * 1024u; // one 256-row tile of the rows
+    const uint32_t a_piece = I8 ? 2048u : 1024u;                              // one k-slice inside a row group
+    const uint32_t a_soff = I8 ? (wave >> 1) * a_chunks * 1024u + (wave & 1u) * 512u : wave * KS * 1024u;
+    const uint32_t a_lds = wave * KU * 1024u;
+    const uintptr_t a_end = (uintptr_t)A + a_bytes;
     // query pieces: wave w moves (32-query group w >> 2 [+ 2 for the second column], k-slice w & 3)
     const uint32_t b_soff = ((wave >> 2) * KS + (wave & 3u)) * 1024u, b_lds = (A_UNITS + wave) * 1024u;
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)ring;
     uintptr_t nx_base = (uintptr_t)A + (uintptr_t)tile0 * tile_bytes;
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, 0xffffffff, 0x00020000);
-    uint32_t nx_idx = 0, nx_koff = 0, nx_slot = 0;
+    uint32_t nx_idx = 0, nx_koff = 0, nx_slot = 0; // nx_koff: K offset in the query mirror (rows: x a_piece / 1024)
     auto stage = [&]() { // issue the next stage into the next ring slot (past the end: re-issue the last one)
-        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, 0xffffffff, 0x00020000);
+        uint32_t bound = 0xffffffffu; // rb64 source: bounded by the allocation (K padding / missing row-blocks read 0)
+        if (I8) {
+            const uintptr_t left = nx_base < a_end ? a_end - nx_base : 0;
+            bound = left < 0xffffffffu ? (uint32_t)left : 0xffffffffu;
+        }
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)nx_base, 0, bound, 0x00020000);
         const uint32_t slot_base = ring_base + nx_slot * (UNITS * 1024u);
+        const uint32_t a_koff = I8 ? nx_koff * 2u : nx_koff;
 #pragma unroll
         for (uint32_t u = 0; u < KU; ++u) {
             uint32_t a = slot_base + a_lds + u * 1024u;
             asm volatile("" : "+s"(a)); // LDS destination laundered: see mfma_prefilter256_kernel
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
-                                                     (int)lane16, (int)(a_soff + u * 1024u + nx_koff), 0, 0);
+                                                     (int)lane16a, (int)(a_soff + u * a_piece + a_koff), 0, 0);
         }
 #pragma unroll
         for (uint32_t col = 0; col < (uint32_t)NCOL; ++col) {
@@ -766,12 +781,12 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
         }
     };
 
-    f32x16 acc[NI];
+    typename std::conditional<I8, i32x16, f32x16>::type acc[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            acc[ni][r] = 0.0f;
+            acc[ni][r] = 0;
     const float ninf = __uint_as_float(0xff800000u);
     float m1[NI], m2[NI], m3[NI];
 #pragma unroll
@@ -787,8 +802,11 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
-            cq[ni] = q < nq ? 2.0f * q_norm[q] : 0.0f;
-            ce[ni] = q < nq ? q_eps[q] : 0.0f;
+            if (q < nq) { // as in mfma_prefilter256_kernel
+                const float a2 = 2.0f * q_norm[q];
+                cq[ni] = I8 ? a2 * q_scale[q] / i8_scale : a2;
+                ce[ni] = I8 ? a2 * q_eps[q] : q_eps[q];
+            }
         }
     }
     auto insert3 = [&](int ni, float sp) __attribute__((always_inline)) {
@@ -807,6 +825,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                 const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
                 bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
                 bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
+            } else if (I8) {
+                const float4 p = *(const float4 *)(inv_rn + row4);
+                bn[0] = p.x, bn[1] = p.y, bn[2] = p.z, bn[3] = p.w;
             }
 #pragma unroll
             for (int rl = 0; rl < 4; ++rl) {
@@ -814,14 +835,18 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                 const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | (mi << 4) | (uint32_t)r));
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    float v = acc[ni][r];
-                    if (MODE == 1)
+                    float v = (float)acc[ni][r];
+                    if (I8 && MODE == 1)
+                        v = __builtin_fmaf(v, cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
+                    else if (I8)
+                        v = v * bn[rl];
+                    else if (MODE == 1)
                         v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
                     float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
                     if (ragged && row4 + (uint32_t)rl >= n_rows)
                         sp = ninf;
                     insert3(ni, sp);
-                    acc[ni][r] = 0.0f;
+                    acc[ni][r] = 0;
                 }
             }
         }
@@ -893,8 +918,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
         for (uint32_t ks = 0; ks < KU; ++ks) {
 #pragma unroll
             for (uint32_t ni = 0; ni < (uint32_t)NI; ++ni)
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bf16x8(fa[ks]), frag_bf16x8(fb[ni * 4u + ks]),
-                                                                  acc[ni], 0, 0, 0);
+                acc[ni] = mfma_32x32(__builtin_bit_cast(uint4, fa[ks]), __builtin_bit_cast(uint4, fb[ni * 4u + ks]),
+                                     acc[ni]);
         }
         if (++cur_kt == KT) {
             const uint32_t ts = cur_ts;
@@ -1272,8 +1297,9 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
     static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
     if (skinny_on && nq <= 128u) {
 #define VFSX_SKINNY(MODE, NCOL)                                                                                    \
-    hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL>), dim3(g.n_strips), dim3(512), 0, s, mirror,   \
-                       qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps)
+    hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, false>), dim3(g.n_strips), dim3(512), 0, s,    \
+                       mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm,      \
+                       q_eps, 0u, (uint64_t)0, (const float *)nullptr, (const float *)nullptr, 1.0f)
         if (nq <= 64u) {
             if (euclid)
                 VFSX_SKINNY(1, 1);
@@ -1311,6 +1337,27 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
     const uint32_t n_qtiles = (nq + 255u) / 256u;
     uint32_t qpx = 1;
     const dim3 grid = pf_grid(g, n_qtiles, (size_t)256u * g.k_pad, &qpx);
+    static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
+    if (skinny_on && nq <= 128u) {
+#define VFSX_SKINNY(MODE, NCOL)                                                                                    \
+    hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, true>), dim3(g.n_strips), dim3(512), 0, s,     \
+                       corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists,            \
+                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale,  \
+                       i8_scale)
+        if (nq <= 64u) {
+            if (euclid)
+                VFSX_SKINNY(1, 1);
+            else
+                VFSX_SKINNY(0, 1);
+        } else {
+            if (euclid)
+                VFSX_SKINNY(1, 2);
+            else
+                VFSX_SKINNY(0, 2);
+        }
+#undef VFSX_SKINNY
+        return hipGetLastError();
+    }
 #define VFSX_PF256(MODE)                                                                                           \
     hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, true>), grid, dim3(512), 0, s,   \
                        corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,  \
