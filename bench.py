@@ -175,7 +175,16 @@ def main(argv=None) -> int:
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
-            comm = sharded.Comm.bootstrap(local_rank)  # the library's own RCCL communicator (vfsx_comm_*)
+            try:  # the library's own RCCL communicator (vfsx_comm_*)
+                comm = sharded.Comm.bootstrap(local_rank)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench rank {rank}] vfsx_comm bootstrap failed ({e}); torch.distributed all-gather instead",
+                      file=sys.stderr, flush=True)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         else:
             dist.init_process_group(backend)
 
@@ -320,9 +329,12 @@ def main(argv=None) -> int:
     if world > 1:
         out["scaling_note"] = ("rows_per_gpu is fixed, so the corpus grows with N: ideal weak scaling is a constant "
                                "value (queries/s against the whole corpus) and N x hbm_gbps_aggregate")
-        out["rccl_ranks"] = (int(vfs_amd.load().vfsx_comm_world(comm.handle)) if comm is not None else None)
+        out["rccl_ranks"] = (int(vfs_amd.load().vfsx_comm_world(comm.handle)) if comm is not None else
+                             (dist.get_world_size() if dist.get_backend() == "nccl" else None))
         out["collective"] = ("vfsx_comm_merge_hits: ncclAllGather (RCCL) + device merge, one per step" if comm is not None
-                             else f"torch.distributed {dist.get_backend()} rehearsal (not RCCL)")
+                             else ("torch.distributed all_gather_into_tensor (RCCL) + device merge, one per step "
+                                   "(vfsx_comm bootstrap failed: see stderr)" if dist.get_backend() == "nccl" else
+                                   f"torch.distributed {dist.get_backend()} rehearsal (not RCCL)"))
     if metric == 4:
         out["dtype"] = "int32 dot4 on i8 (integer-domain extension) + f32 sqrt/div"
     if latency:

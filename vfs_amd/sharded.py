@@ -67,9 +67,17 @@ class Comm:
     def bootstrap(cls, device: int, group=None) -> "Comm":
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:  # a failure on rank 0 must not leave the other ranks waiting in the broadcast
+            try:
+                box = [(cls.unique_id(), None)]
+            except Exception as e:  # noqa: BLE001 -- re-raised on every rank below
+                box = [(None, f"{type(e).__name__}: {e}")]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(rank, world, box[0], device)
+        uid, err = box[0]
+        if uid is None:
+            raise RuntimeError(f"vfsx_comm_unique_id failed on rank 0: {err}")
+        return cls(rank, world, uid, device)
 
     @property
     def handle(self):
