@@ -47,17 +47,21 @@ WORKLOADS = {
                                            "own Simd path accepts, rank.rs:303)"),
     "c5": (12_500_000, 768, False, 0, 32, "C5 shard 12.5Mx768 f32 Euclidean per GPU (100Mx768 over 8 GPUs), "
                                           "single-query scan, RCCL all-gather top-k merge"),
-    "c4e": (10_000_000, 1024, False, 0, 4096, "4096-query batch x 10Mx1024 Euclidean as Q.X^T on bf16 MFMA + per-row "
-                                              "upper-bound epilogue + fused top-k, exact f32 re-score (extension of C4 to "
-                                              "the Euclidean metric)"),
-    "c4": (10_000_000, 1024, False, 1, 4096, "C4 4096-query batch x 10Mx1024 Cosine as Q.X^T on bf16 MFMA + fused top-k, "
-                                             "exact f32 re-score"),
+    "c4e": (10_000_000, 1024, False, 0, 4096, "4096-query batch x 10Mx1024 f32 Euclidean as Q.X^T on MFMA (the library's "
+                                              "choice of mirror) + per-row upper-bound epilogue + fused top-k, exact f32 "
+                                              "re-score (extension of C4 to the Euclidean metric)"),
+    "c4": (10_000_000, 1024, False, 1, 4096, "C4 4096-query batch x 10Mx1024 f32 Cosine as Q.X^T on MFMA (the library's "
+                                             "choice of mirror: int8 with per-row scales unless the data says bf16) + "
+                                             "fused top-k, exact f32 re-score"),
+    "c4bf16": (10_000_000, 1024, False, 1, 4096, "C4 with the bf16 mirror forced: Q.X^T on bf16 MFMA + fused top-k, exact "
+                                                 "f32 re-score"),
+    "c4ebf16": (10_000_000, 1024, False, 0, 4096, "C4 Euclidean with the bf16 mirror forced"),
     "c4i8": (10_000_000, 1024, True, 1, 4096, "4096-query batch x 10Mx1024 int8 QuantizedVector Cosine: int8 MFMA over the "
                                               "rb64 corpus itself (no mirror) + fused top-k, exact f32 re-score"),
     "c3b": (10_000_000, 128, True, 0, 4096, "C3 in batches: 4096 queries x 10Mx128 int8 QuantizedVector Euclidean, int8 "
                                             "MFMA over the rb64 corpus + upper-bound epilogue, exact f32 re-score"),
 }
-MFMA_WORKLOADS = ("c4", "c4e", "c4i8", "c3b")
+MFMA_WORKLOADS = ("c4", "c4e", "c4bf16", "c4ebf16", "c4i8", "c3b")
 METRIC_NAMES = ["euclidean", "cosine", "simd_euclidean", "simd_cosine", "euclidean_i8_domain"]
 
 
@@ -199,7 +203,8 @@ def main(argv=None) -> int:
     corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
     corpus.set_row_base(rank * rows)
     if mfma:
-        corpus.enable_mfma(True)
+        corpus.enable_mfma(True, mirror="bf16" if workload.endswith("bf16") else "auto")
+        mirror_kind, mirror_rx = corpus.mfma_mirror()
 
     dbg("corpus filled")
     n_q = (args.steps + args.warmup) * qps_step
@@ -344,9 +349,10 @@ def main(argv=None) -> int:
                      "hbm_gib": round(props.total_memory / 2**30, 1),
                      "peak_source": "MI355X_MICROARCH.md (8 TB/s HBM3E, 2.5 PFLOP/s dense bf16)"}
     if mfma:
-        mfma_peak = MFMA_PEAK_I8_TOPS if quantize else MFMA_PEAK_TFLOPS
+        i8_mfma = mirror_kind in ("int8", "int8-store")
+        mfma_peak = MFMA_PEAK_I8_TOPS if i8_mfma else MFMA_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "achieved": round(tflops, 1), "peak": mfma_peak,
-                           "unit": "TOP/s" if quantize else "TFLOP/s",
+                           "unit": "TOP/s" if i8_mfma else "TFLOP/s",
                            "frac": round(tflops / mfma_peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": "mfma_prefilter256_kernel", "avg_kernel_ms": round(avg_ms, 4),
                            "algorithmic_flops_per_launch": flops, "launches_timed": int(scan_launches)}
@@ -354,8 +360,10 @@ def main(argv=None) -> int:
             out.pop(key, None)  # HBM figures describe the single-query scan, not a matrix-core batch
         out["mfma_queries"] = int(mq)
         out["mfma_fallback_queries"] = int(mf)
-        out["dtype"] = ("int8 MFMA (i32 accumulate) prefilter + f32 exact re-score" if quantize else
+        out["dtype"] = ("int8 MFMA (i32 accumulate) prefilter + f32 exact re-score" if i8_mfma else
                         "bf16 MFMA prefilter + f32 exact re-score")
+        out["mfma_operand"] = {"kind": mirror_kind, "measured_row_residual": round(mirror_rx, 6),
+                               "after_run": corpus.mfma_mirror()[0]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, rows, dim, quantize, metric, k)

@@ -331,17 +331,27 @@ int vfsx_comm_merge_hits(vfsx_comm *comm, const vfsx_hit *d_local, uint32_t nq, 
 /*
  * Many-query batches on the matrix cores (no reference counterpart: the reference has no
  * multi-query API, rank.rs:90; a batch is defined as the single-query result per query).
- * Enabling builds a bf16 mirror of the corpus (+2 bytes per element of HBM).  Afterwards
- * vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 (f32 stores) / 8 (int8 stores)
- * queries with k <= 64 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the exact scan)
- * through Q.X^T on MFMA + an exact sequential re-score of the surviving candidates + a
- * rigorous bound check, and re-run the exact scan for any query the check cannot clear:
- * the results stay bit-identical to the single-query scan.  On this path
- * vfsx_search_device synchronises `stream` once (to read the per-query check flags).
+ * enable: 0 = off, 1 = on (mirror chosen by the library), 2 = on with a bf16 mirror, 3 = on with an int8 mirror.
+ * An f32 store gets a mirror the matrix cores multiply: int8 with one scale per row (+1 byte per element, read by
+ * v_mfma_i32_32x32x32_i8 at twice the bf16 rate) or bf16 (+2 bytes per element); with 1 the library starts on int8
+ * and moves to bf16 for good when the rows' measured quantization residual is large or a batch sends more than 1/8 of
+ * its queries back.  An int8 store needs no mirror: its rb64 rows are the int8 operand (+12 bytes per row).
+ * Afterwards vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 queries with
+ * k <= 64 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the
+ * exact scan) through Q.X^T on MFMA + an exact sequential re-score of the surviving candidates + a bound check built
+ * from the measured rounding / quantization residuals, and re-run the exact scan for any query the check cannot
+ * clear: the results stay bit-identical to the single-query scan.  On this path vfsx_search_device synchronises
+ * `stream` once (to read the per-query check flags).
  */
 int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable);
 /* Queries answered through the MFMA path and how many of them fell back to the exact scan. */
 int vfsx_corpus_mfma_stats(vfsx_corpus *c, uint64_t *queries, uint64_t *fallbacks, int reset);
+/*
+ * What the matrix-core path of this corpus multiplies right now (no reference counterpart): *kind = 0 path off,
+ * 1 bf16 mirror, 2 int8 mirror of an f32 store, 3 the int8 store itself; *residual = R_x, the largest measured
+ * rounding / quantization residual || x/||x|| - mirror(x) ||_2 over the rows (0 for kind 3 and before the first build).
+ */
+int vfsx_corpus_mfma_mirror(vfsx_corpus *c, int *kind, float *residual);
 
 /*
  * Profiling aid: when enabled, vfsx_search / vfsx_search_device bracket the scan

@@ -86,6 +86,7 @@ extern "C" {
     // ---- many-query batches on the matrix cores, profiling
     pub fn vfsx_corpus_enable_mfma(c: *mut VfsxCorpus, enable: c_int) -> c_int;
     pub fn vfsx_corpus_mfma_stats(c: *mut VfsxCorpus, queries: *mut u64, fallbacks: *mut u64, reset: c_int) -> c_int;
+    pub fn vfsx_corpus_mfma_mirror(c: *mut VfsxCorpus, kind: *mut c_int, residual: *mut f32) -> c_int;
     pub fn vfsx_corpus_set_profiling(c: *mut VfsxCorpus, enabled: c_int) -> c_int;
     pub fn vfsx_corpus_scan_time_ms(c: *mut VfsxCorpus, total_ms: *mut f64, launches: *mut u64, reset: c_int) -> c_int;
 }
@@ -152,6 +153,15 @@ pub struct Corpus {
 }
 
 unsafe impl Send for Corpus {}
+
+/// Argument of `vfsx_corpus_enable_mfma` beyond on / off (include/vfsx.h).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+#[repr(i32)]
+pub enum MfmaMirror {
+    Auto = 1,
+    Bf16 = 2,
+    Int8 = 3,
+}
 
 impl Corpus {
     pub fn new(dim: usize, quantize: bool, capacity_rows: u64, device: i32) -> io::Result<Self> {
@@ -308,9 +318,21 @@ impl Corpus {
         check(vfsx_search_device_noalloc(self.h, d_queries, nq, k, metric as c_int, d_hits, stream))
     }
 
-    /// Many-query batches on the matrix cores (results unchanged; +2 bytes per element of HBM).
+    /// Many-query batches on the matrix cores (results unchanged).  f32 stores get a mirror chosen by the library
+    /// (int8 with per-row scales, +1 byte per element, or bf16, +2); int8 stores need none.
     pub fn enable_mfma(&mut self, on: bool) -> io::Result<()> {
         check(unsafe { vfsx_corpus_enable_mfma(self.h, on as c_int) })
+    }
+    /// The same with the mirror of an f32 store forced: `MfmaMirror::Bf16` or `MfmaMirror::Int8`.
+    pub fn enable_mfma_with(&mut self, mirror: MfmaMirror) -> io::Result<()> {
+        check(unsafe { vfsx_corpus_enable_mfma(self.h, mirror as c_int) })
+    }
+    /// (what the matrix-core path multiplies: 0 off, 1 bf16 mirror, 2 int8 mirror, 3 the int8 store itself; the rows'
+    /// largest measured rounding / quantization residual)
+    pub fn mfma_mirror(&mut self) -> io::Result<(i32, f32)> {
+        let (mut kind, mut res) = (0 as c_int, 0f32);
+        check(unsafe { vfsx_corpus_mfma_mirror(self.h, &mut kind, &mut res) })?;
+        Ok((kind as i32, res))
     }
     /// (queries answered through the matrix-core path, of which sent back to the exact scan)
     pub fn mfma_stats(&mut self, reset: bool) -> io::Result<(u64, u64)> {

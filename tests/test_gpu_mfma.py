@@ -8,6 +8,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["int8", "bf16"])
+def mirror_kind(request, monkeypatch):
+    """Every test of this module runs with both mirrors an f32 store can have (int8 with per-row scales, bf16);
+    int8 stores ignore it (they are their own operand).  VFSX_MFMA_MIRROR is read by vfsx_corpus_enable_mfma."""
+    monkeypatch.setenv("VFSX_MFMA_MIRROR", request.param)
+    return request.param
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -403,4 +411,71 @@ def test_mfma_adversarial_bf16_midpoints(oracle, below, int8, metric, k):
         assert (bits(dist[qi]) == bits(od)).all()
         if qi < len(targets):
             assert ids[qi][0] == targets[qi] + 1  # the twin row (ids are 1-based scan positions)
+    c.close()
+
+
+def test_mfma_mirror_choice_and_auto_policy(oracle, monkeypatch):
+    """vfsx_corpus_mfma_mirror reports what the path multiplies; "auto" starts on the int8 mirror and (a) builds the
+    bf16 mirror instead when the rows' measured int8 residual exceeds 2^-6 (one dominant component per row: int8
+    keeps 7 bits of the LARGEST component, so the small ones vanish), (b) moves to bf16 for good when a batch sends
+    more than 1/8 of its queries back.  Results equal the exact scan's throughout."""
+    import vfs_amd
+    monkeypatch.delenv("VFSX_MFMA_MIRROR", raising=False)
+    rng = np.random.default_rng(4242)
+    n, d = 30000, 256
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (64, d)).astype(np.float32)
+
+    def same_as_exact(c, qs, k=10, metric=1):
+        c.mfma_stats(reset=True)
+        im, dm, cm = c.search_batch(qs, k, metric)
+        nq_m, fb = c.mfma_stats()
+        assert nq_m == len(qs)
+        kind = c.mfma_mirror()[0]
+        c.enable_mfma(False)
+        ie, de, ce = c.search_batch(qs, k, metric)
+        assert (im == ie).all() and (bits(dm) == bits(de)).all() and (cm == ce).all()
+        return fb, kind
+
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    assert c.mfma_mirror() == ("off", 0.0)
+    c.enable_mfma(True)
+    kind, rx = c.mfma_mirror()
+    assert kind == "int8" and 0.001 < rx < 0.008  # uniform rows: sqrt(3) / (127 sqrt(12)) = 0.0039
+    fb, kind = same_as_exact(c, queries)
+    assert kind == "int8" and fb == 0
+    c.enable_mfma(True, mirror="bf16")
+    kind, rx = c.mfma_mirror()
+    assert kind == "bf16" and 0.0005 < rx < 0.004  # 2^-9 / sqrt(3) = 0.0011
+    same_as_exact(c, queries)
+    c.close()
+
+    # (a) heavy-tailed rows: one component 300x the rest
+    spiky = rows.copy()
+    spiky[np.arange(n), rng.integers(0, d, n)] *= 300.0
+    c = vfs_amd.Corpus(d)
+    c.append(spiky)
+    c.enable_mfma(True, mirror="int8")
+    kind, rx_forced = c.mfma_mirror()
+    assert kind == "int8" and rx_forced > 2.0 ** -6
+    same_as_exact(c, queries[:16])  # forced int8 on such rows: still the exact result (through fallbacks)
+    c.enable_mfma(True)
+    assert c.mfma_mirror()[0] == "bf16"
+    same_as_exact(c, queries[:16])
+    c.close()
+
+    # (b) near-duplicate clusters: hundreds of rows inside the int8 margin of the k-th neighbour
+    centers = rng.uniform(-1, 1, (30, d)).astype(np.float32)
+    dup = (centers[rng.integers(0, 30, n)] + rng.normal(0, 2e-3, (n, d))).astype(np.float32)
+    qd = (centers[rng.integers(0, 30, 64)] + rng.normal(0, 2e-3, (64, d))).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(dup)
+    c.enable_mfma(True)
+    assert c.mfma_mirror()[0] == "int8"
+    fb, _ = same_as_exact(c, qd)
+    c.enable_mfma(True)  # (same_as_exact switched the path off; the choice made by the batch above persists)
+    if fb * 8 > len(qd):
+        assert c.mfma_mirror()[0] == "bf16"
+    same_as_exact(c, qd)
     c.close()

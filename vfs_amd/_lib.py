@@ -29,7 +29,7 @@ SYMBOLS = (
     "vfsx_corpus_get_rows_f32", "vfsx_corpus_get_rows_raw", "vfsx_corpus_get_ids",
     "vfsx_corpus_fill_synthetic", "vfsx_search", "vfsx_search_device", "vfsx_search_device_noalloc",
     "vfsx_merge_hits_device", "vfsx_merge_hits_host", "vfsx_corpus_set_profiling",
-    "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats",
+    "vfsx_corpus_scan_time_ms", "vfsx_corpus_enable_mfma", "vfsx_corpus_mfma_stats", "vfsx_corpus_mfma_mirror",
     "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_load_log_range", "vfsx_corpus_get_metadata_json",
     "vfsx_comm_unique_id", "vfsx_comm_init", "vfsx_comm_destroy", "vfsx_comm_rank", "vfsx_comm_world",
     "vfsx_comm_rccl_version", "vfsx_search_sharded", "vfsx_search_sharded_host", "vfsx_comm_merge_hits",
@@ -116,6 +116,7 @@ def load() -> C.CDLL:
     lib.vfsx_corpus_get_metadata_json.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, u64p]
     lib.vfsx_corpus_enable_mfma.argtypes = [vp, C.c_int]
     lib.vfsx_corpus_mfma_stats.argtypes = [vp, u64p, u64p, C.c_int]
+    lib.vfsx_corpus_mfma_mirror.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.vfsx_corpus_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
     lib.vfsx_comm_unique_id.argtypes = [vp]
     lib.vfsx_comm_init.restype = vp

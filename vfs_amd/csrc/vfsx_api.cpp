@@ -184,6 +184,13 @@ struct vfsx_corpus {
     DeviceBuf<float> fb_queries;
     DeviceBuf<vfsx_hit> fb_hits;
     bool mirror_bad = false;
+    // f32 stores: which mirror the prefilter multiplies.  bf16 (2 B / element) or int8 with a scale per row (1 B /
+    // element, twice the MFMA rate, ~3.5x the quantization residual).  Auto starts on int8 and moves to bf16 for good
+    // when the measured residual R_x is large (heavy-tailed rows) or a batch sends too many queries back.
+    enum MirrorKind { kMirrorBf16 = 0, kMirrorI8 = 1 };
+    int mirror_kind = kMirrorI8;
+    int mirror_pref = 0; // 0 auto, 1 bf16, 2 int8 (vfsx_corpus_enable_mfma's argument - 1, or VFSX_MFMA_MIRROR)
+    float mirror_rx = 0.0f;
     uint32_t mfma_min_batch = 4;
     uint32_t mfma_kp_override = 0; // VFSX_MFMA_KP: first-pass candidates per query (0 = by k)
     DeviceBuf<uint8_t> q_mirror;
@@ -638,45 +645,68 @@ void free_mirror(vfsx_corpus *c)
 // sequential sums of d terms, the row norm b vs ||x||, the query norm a vs ||q||, and the epilogue's roundings
 float mfma_gamma(uint32_t k_pad) { return ((float)k_pad + 32.0f) * 0x1p-23f; }
 
-// (re)build what the batch path keeps per row when rows were appended since: f32 stores, the bf16 mirror; int8
-// stores, only the per-row factors (the prefilter multiplies the rb64 corpus itself)
+// (re)build what the batch path keeps per row when rows were appended since: f32 stores, the bf16 or int8 mirror;
+// int8 stores, only the per-row factors (the prefilter multiplies the rb64 corpus itself)
+constexpr float kMirrorI8MaxResidual = 0x1p-6f; // auto: above this R_x the int8 mirror's margin is too wide
+
+bool mirror_is_i8(const vfsx_corpus *c) { return c->dtype == VFSX_F32 && c->mirror_kind == vfsx_corpus::kMirrorI8; }
+bool prefilter_is_i8(const vfsx_corpus *c) { return c->dtype == VFSX_I8 || mirror_is_i8(c); }
+uint32_t mirror_i8_chunks(const vfsx_corpus *c) { return (c->dim + 15u) / 16u; }
+
 void ensure_mirror(vfsx_corpus *c, hipStream_t s)
 {
-    const bool i8 = c->dtype == VFSX_I8;
     if (c->mirror_rows == c->n_rows && c->d_rn2)
         return;
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
-    if (g.mirror_bytes > c->mirror_bytes) {
-        free_mirror(c);
-        HIP_CHECK(hipMalloc((void **)&c->d_mirror, g.mirror_bytes));
-        c->mirror_bytes = g.mirror_bytes;
-    }
-    if (!c->d_mirror_stats)
-        HIP_CHECK(hipMalloc((void **)&c->d_mirror_stats, 2 * sizeof(uint32_t)));
-    HIP_CHECK(hipMemsetAsync(c->d_mirror_stats, 0, 2 * sizeof(uint32_t), s));
-    if (!i8)
-        HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror,
-                                           (uint32_t)c->n_rows, c->dim, c->d_chunks, g, c->d_mirror_stats, s));
-    const size_t n_pad = (size_t)g.n_rowtiles * 256u; // Euclidean batches: (b, b^2 (1 - gamma)) per row
-    if (n_pad > c->rn2_rows) {
-        if (c->d_rn2)
-            (void)hipFree(c->d_rn2);
-        if (c->d_inv_rn)
-            (void)hipFree(c->d_inv_rn);
-        c->d_rn2 = nullptr;
-        c->d_inv_rn = nullptr;
-        c->rn2_rows = 0;
-        HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
-        if (i8)
+    for (;;) {
+        const bool i8 = prefilter_is_i8(c);
+        const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
+        const size_t n_pad = (size_t)g.n_rowtiles * 256u;
+        const size_t want = c->dtype == VFSX_I8 ? 0
+                            : (mirror_is_i8(c) ? (n_pad / 64u) * mirror_i8_chunks(c) * 1024u : g.mirror_bytes);
+        if (want > c->mirror_bytes) {
+            free_mirror(c);
+            HIP_CHECK(hipMalloc((void **)&c->d_mirror, want));
+            c->mirror_bytes = want;
+        }
+        if (!c->d_mirror_stats)
+            HIP_CHECK(hipMalloc((void **)&c->d_mirror_stats, 2 * sizeof(uint32_t)));
+        HIP_CHECK(hipMemsetAsync(c->d_mirror_stats, 0, 2 * sizeof(uint32_t), s));
+        if (n_pad > c->rn2_rows) { // Euclidean batches: (b, b^2 (1 - gamma)) per row; int8 operands: the row factor
+            if (c->d_rn2)
+                (void)hipFree(c->d_rn2);
+            if (c->d_inv_rn)
+                (void)hipFree(c->d_inv_rn);
+            c->d_rn2 = nullptr;
+            c->d_inv_rn = nullptr;
+            c->rn2_rows = 0;
+            HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
             HIP_CHECK(hipMalloc((void **)&c->d_inv_rn, n_pad * sizeof(float)));
-        c->rn2_rows = n_pad;
+            c->rn2_rows = n_pad;
+        }
+        if (mirror_is_i8(c)) {
+            HIP_CHECK(hipMemsetAsync(c->d_mirror, 0, want, s)); // rows beyond n_rows are read (and masked)
+            HIP_CHECK(hipMemsetAsync(c->d_inv_rn, 0, n_pad * sizeof(float), s));
+            HIP_CHECK(vfsx::launch_mfma_mirror_i8(c->d_corpus, c->d_norms, c->d_mirror, c->d_inv_rn, (uint32_t)c->n_rows,
+                                                  c->d_chunks, mirror_i8_chunks(c), g.k_pad, c->d_mirror_stats, s));
+        } else if (c->dtype == VFSX_F32) {
+            HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror,
+                                               (uint32_t)c->n_rows, c->dim, c->d_chunks, g, c->d_mirror_stats, s));
+        }
+        HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad, mfma_gamma(g.k_pad),
+                                                  c->d_rn2, c->dtype == VFSX_I8 ? c->d_inv_rn : nullptr, c->scale,
+                                                  c->d_mirror_stats, s));
+        uint32_t st[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(st, c->d_mirror_stats, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        c->mirror_bad = st[0] != 0;
+        std::memcpy(&c->mirror_rx, &st[1], sizeof(float));
+        if (mirror_is_i8(c) && c->mirror_pref == 0 && !c->mirror_bad && c->mirror_rx > kMirrorI8MaxResidual) {
+            c->mirror_kind = vfsx_corpus::kMirrorBf16; // heavy-tailed rows: the bf16 mirror's bound is ~3.5x tighter
+            c->mirror_bytes = 0;                       // (forces the reallocation above)
+            continue;
+        }
+        break;
     }
-    HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad, mfma_gamma(g.k_pad),
-                                              c->d_rn2, c->d_inv_rn, c->scale, c->d_mirror_stats, s));
-    uint32_t bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, c->d_mirror_stats, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    c->mirror_bad = bad != 0;
     c->mirror_rows = c->n_rows;
 }
 
@@ -688,9 +718,13 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 {
     use_device(c);
     ensure_mirror(c, s);
-    const bool i8 = c->dtype == VFSX_I8;
+    const bool i8 = prefilter_is_i8(c);
     const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
     const size_t qm_elem = i8 ? 1u : 2u; // query mirror: int8 or bf16
+    // the int8 prefilter's row operand: the int8 store itself, or the int8 mirror of an f32 store
+    const uint4 *a_rows = mirror_is_i8(c) ? c->d_mirror : c->d_corpus;
+    const uint32_t a_chunks = mirror_is_i8(c) ? mirror_i8_chunks(c) : c->d_chunks;
+    const uint64_t a_bytes = mirror_is_i8(c) ? c->mirror_bytes : c->corpus_bytes(c->capacity);
     // first-pass candidates per query; queries with more rows above their safety margin are decided again from
     // 256 candidates in the second device pass below (C4, k = 10: 64 -> 68.3 ms per batch, 128 -> 70.6 ms, no
     // query left for the exact scan either way)
@@ -731,7 +765,8 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         if (i8)
             HIP_CHECK(vfsx::launch_mfma_query_prep_i8(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
                                                       c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0,
-                                                      c->q_scale.p + q0, s));
+                                                      c->q_scale.p + q0, mirror_is_i8(c) ? c->d_mirror_stats : nullptr,
+                                                      s));
         else
             HIP_CHECK(vfsx::launch_mfma_query_prep(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
                                                    c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0,
@@ -739,10 +774,9 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         size_t slot = 0;
         prof_begin(c, s, slot);
         if (i8)
-            HIP_CHECK(vfsx::launch_mfma_prefilter_i8(c->d_corpus, c->d_chunks, c->corpus_bytes(c->capacity),
-                                                     c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
+            HIP_CHECK(vfsx::launch_mfma_prefilter_i8(a_rows, a_chunks, a_bytes, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn, euclid,
                                                      c->d_rn2, c->d_inv_rn, c->q_norm.p + q0, c->q_eps.p + q0,
-                                                     c->q_scale.p + q0, c->scale, s));
+                                                     c->q_scale.p + q0, s));
         else
             HIP_CHECK(vfsx::launch_mfma_prefilter(c->d_mirror, c->q_mirror.p, c->cand.p, (uint32_t)c->n_rows, g, qn,
                                                   euclid, c->d_rn2, c->q_norm.p + q0, c->q_eps.p + q0, s));
@@ -790,7 +824,13 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         uint32_t flagged = 0;
         for (uint32_t q = 0; q < nq; ++q)
             flagged += c->h_flags[q] ? 1u : 0u;
-        if (flagged * 2u > nq) {
+        if (mirror_is_i8(c) && c->mirror_pref == 0 && flagged * 8u > nq) {
+            // auto: the int8 mirror's wider margin sends too many of this data's queries back: bf16 mirror from the
+            // next batch on (rebuilt by ensure_mirror), for good
+            c->mirror_kind = vfsx_corpus::kMirrorBf16;
+            c->mirror_rows = 0;
+            c->mirror_bytes = 0;
+        } else if (flagged * 2u > nq) {
             c->mfma_backoff_next = std::min<uint32_t>(c->mfma_backoff_next * 2u + 1u, 63u);
             c->mfma_backoff = c->mfma_backoff_next;
         } else {
@@ -1251,12 +1291,42 @@ int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
     return guarded([&] {
         checked(c);
         use_device(c);
+        if (enable < 0 || enable > 3)
+            fail(VFSX_ERR_INVALID_VECTOR, "vfsx_corpus_enable_mfma: enable must be 0 (off), 1 (auto), 2 (bf16 mirror) or 3 (int8 mirror)");
         c->mfma_enabled = enable != 0;
         c->mfma_backoff = c->mfma_backoff_next = 0;
-        if (!enable)
+        if (!enable) {
             free_mirror(c);
-        else if (c->n_rows)
+            return;
+        }
+        int pref = enable - 1; // 0 auto, 1 bf16, 2 int8
+        if (pref == 0) {
+            const char *e = std::getenv("VFSX_MFMA_MIRROR");
+            if (e && std::strcmp(e, "bf16") == 0)
+                pref = 1;
+            else if (e && std::strcmp(e, "int8") == 0)
+                pref = 2;
+        }
+        const int kind = pref == 1 ? vfsx_corpus::kMirrorBf16 : vfsx_corpus::kMirrorI8;
+        if (pref != c->mirror_pref || (pref != 0 && kind != c->mirror_kind)) {
+            c->mirror_pref = pref;
+            c->mirror_kind = kind; // (auto starts over on the int8 mirror)
+            c->mirror_rows = 0;
+            c->mirror_bytes = 0;
+        }
+        if (c->n_rows)
             ensure_mirror(c, c->stream);
+    });
+}
+
+int vfsx_corpus_mfma_mirror(vfsx_corpus *c, int *kind, float *residual)
+{
+    return guarded([&] {
+        checked(c);
+        if (kind)
+            *kind = !c->mfma_enabled ? 0 : (c->dtype == VFSX_I8 ? 3 : (mirror_is_i8(c) ? 2 : 1));
+        if (residual)
+            *residual = c->mfma_enabled && c->dtype == VFSX_F32 && c->mirror_rows ? c->mirror_rx : 0.0f;
     });
 }
 

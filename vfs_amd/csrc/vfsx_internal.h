@@ -140,12 +140,19 @@ hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t 
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
                                      float *inv, float i8_scale, uint32_t *stats, hipStream_t s);
 // int8 stores: no mirror -- the prefilter reads the rb64 corpus; the queries are quantized per batch
+// stats: nullptr for an int8 store (exact rows), the mirror's stats for an int8 mirror of an f32 store (R_x)
 hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                     int *q_bad, float *q_norm, float *q_eps, float *q_scale, hipStream_t s);
+                                     int *q_bad, float *q_norm, float *q_eps, float *q_scale, const uint32_t *stats,
+                                     hipStream_t s);
+// int8 mirror of an f32 store: rb64 int8 rows (d_chunks8 = ceil(dim / 16) chunks per row; the buffer must cover
+// whole 64-row blocks and be zeroed beforehand), inv_rn[row] = the row's scale, stats[0] / stats[1] as launch_mfma_mirror
+hipError_t launch_mfma_mirror_i8(const uint4 *corpus, const float *row_norms, uint4 *mirror, float *inv_rn,
+                                 uint32_t n_rows, uint32_t d_chunks, uint32_t d_chunks8, uint32_t k_pad,
+                                 uint32_t *stats, hipStream_t s);
 hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint64_t corpus_bytes, const void *q_mirror,
                                     float *cand, uint32_t n_rows, const MfmaGeometry &g, uint32_t nq, int euclid,
                                     const float *rn2, const float *inv_rn, const float *q_norm, const float *q_eps,
-                                    const float *q_scale, float i8_scale, hipStream_t s);
+                                    const float *q_scale, hipStream_t s);
 hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, float *cand, uint32_t n_rows,
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
                                  const float *q_norm, const float *q_eps, hipStream_t s);

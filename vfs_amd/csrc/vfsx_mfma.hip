@@ -157,6 +157,67 @@ __global__ void mfma_residual_kernel(const uint4 *__restrict__ corpus, const flo
         atomicMax(&stats[1], __float_as_uint(r));
 }
 
+// ---- int8 mirror of an f32 store: rb64 int8 rows with a scale per row ------------------------------------
+// x^ = x / b (b = the f32 row norm), s_x = max_j |x^_j| / 127, x~_j = round(x^_j / s_x): the row becomes an int8 row in
+// the rb64 layout of an int8 store (16 k per 16-byte chunk), so that the int8 prefilter reads it exactly as it reads
+// an int8 corpus, at half the bytes per k of the bf16 mirror and twice the MFMA rate.  inv_rn[row] = s_x turns the
+// integer dot product into the cosine up to the query's scale.  The quantization residual r_x = || x^ - s_x x~ ||_2
+// is measured per row like the bf16 one; the corpus maximum goes to stats[1] (error model at the end of the file).
+// One thread per row (lane l of a wave = row 64 b + l: every load and store is a coalesced 1 KiB).
+__global__ void mfma_mirror_i8_kernel(const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
+                                      uint4 *__restrict__ mirror, float *__restrict__ inv_rn, uint32_t n_rows,
+                                      uint32_t d_chunks, uint32_t d_chunks8, uint32_t K, uint32_t *__restrict__ stats)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    float r = 0.0f;
+    if (row < n_rows) {
+        const float b = row_norms[row];
+        const uint4 *p = corpus + (size_t)(row >> 6) * d_chunks * 64u + (row & 63u);
+        uint4 *out = mirror + (size_t)(row >> 6) * d_chunks8 * 64u + (row & 63u);
+        float mx = 0.0f;
+        for (uint32_t c = 0; c < d_chunks; ++c) {
+            const uint4 v = p[(size_t)c * 64u];
+            mx = fmaxf(fmaxf(mx, fabsf(__uint_as_float(v.x))),
+                       fmaxf(fabsf(__uint_as_float(v.y)), fmaxf(fabsf(__uint_as_float(v.z)), fabsf(__uint_as_float(v.w)))));
+        }
+        // division by b > 0 is monotone, so max_j |fl(x_j / b)| = fl(max_j |x_j| / b)
+        const float sx = norm_in_mfma_range(b) ? (mx / b) / 127.0f : 0.0f;
+        if (!(sx > 0.0f) || !norm_in_mfma_range(sx)) {
+            atomicOr(&stats[0], 1u); // zero / out-of-range row: the corpus does not take the batch path
+            inv_rn[row] = 0.0f;
+        } else {
+            float acc = 0.0f;
+            for (uint32_t c8 = 0; c8 < d_chunks8; ++c8) {
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t c = c8 * 4u + u;
+                    if (c < d_chunks) { // (a store's chunks beyond dim hold zeros: they quantize to 0 exactly)
+                        const uint4 v = p[(size_t)c * 64u];
+                        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = __uint_as_float(x[e]) / b;
+                            const float t = fminf(fmaxf(rintf(y / sx), -127.0f), 127.0f);
+                            const float d = y - sx * t;
+                            acc += d * d;
+                            w[u] |= ((uint32_t)(int)t & 0xffu) << (8 * e);
+                        }
+                    }
+                }
+                out[(size_t)c8 * 64u] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            inv_rn[row] = sx;
+            r = residual_norm_bound(acc, K) + 0x1p-22f; // + the f32 roundings inside d (<= 3 * 2^-24 ||x^||)
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        r = fmaxf(r, __shfl_xor(r, o, 64));
+    if ((threadIdx.x & 63u) == 0u && r > 0.0f)
+        atomicMax(&stats[1], __float_as_uint(r));
+}
+
 // ---- Euclidean batches: per-row (b, b^2 (1 - gamma)) with b = the f32 row norm the mirror used ----
 // inv (int8 stores, may be null): 1 / (scale b) = 1 / ||stored bytes||, the factor that turns the integer dot product
 // into the cosine up to the query's own scale (the store holds x = byte / scale, vector.rs:138); stats[0] is raised
@@ -238,7 +299,8 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
 __global__ void mfma_query_prep_i8_kernel(const float *__restrict__ q_in, uint32_t nq, uint32_t dim,
                                           int8_t *__restrict__ q_mirror, uint32_t KS, int *__restrict__ q_bad,
                                           float *__restrict__ q_norm, float *__restrict__ q_eps,
-                                          float *__restrict__ q_scale, float f32_slack)
+                                          float *__restrict__ q_scale, const uint32_t *__restrict__ stats,
+                                          float f32_slack)
 {
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -278,7 +340,10 @@ __global__ void mfma_query_prep_i8_kernel(const float *__restrict__ q_in, uint32
         q_scale[q] = sq;
         // + 2^-22: the f32 roundings inside d (<= 3 * 2^-24 ||q^||) and of q^ itself
         const float r_q = residual_norm_bound(res, KS * 32u) + 0x1p-22f;
-        q_eps[q] = r_q * (1.0f + 0x1p-7f) + f32_slack;
+        // int8 store: the rows are exact (stats == nullptr, R_x = 0).  int8 mirror of an f32 store: the rows carry
+        // R_x = stats[1] too, and |s_x s_q S - x^.q^| <= r_x ||s_q q~|| + ||x^|| r_q <= r_x + r_q + r_x r_q (+ roundings)
+        const float r_x = stats ? __uint_as_float(stats[1]) : 0.0f;
+        q_eps[q] = ((r_x + r_q) * (1.0f + 0x1p-7f) + r_x * r_q) + f32_slack;
     }
 }
 
@@ -367,8 +432,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                                                                 const float *__restrict__ q_eps,
                                                                 uint32_t a_chunks, uint64_t a_bytes,
                                                                 const float *__restrict__ inv_rn,
-                                                                const float *__restrict__ q_scale, float i8_scale,
-                                                                uint32_t qpx, uint32_t n_strips)
+                                                                const float *__restrict__ q_scale, uint32_t qpx,
+                                                                uint32_t n_strips)
 {
     constexpr uint32_t TROWS = 256u, TQ = 256u;
     constexpr uint32_t A_UNITS = 8u * KU, UNITS = 16u * KU;
@@ -480,7 +545,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
     uint32_t keep_mask = ~kIdxMask;
     asm volatile("" : "+v"(keep_mask)); // keep it in a VGPR (see the epilogue)
     uint32_t cur_kt = 0, cur_ts = 0;    // position of the running K-step inside the strip
-    // MODE 1, per query column: bf16: cq = 2a, ce = eps_q;  int8: cq = 2a s_q / scale (times S), ce = 2a eps_q (times ||x||)
+    // MODE 1, per query column: bf16: cq = 2a, ce = eps_q;  int8: cq = 2a s_q (times S ||x|| inv_rn), ce = 2a eps_q (times ||x||)
     float cq[2] = {0.0f, 0.0f}, ce[2] = {0.0f, 0.0f};
     if (MODE == 1) {
 #pragma unroll
@@ -488,7 +553,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             const uint32_t q = qtile * TQ + wave_n * 64u + (uint32_t)ni * 32u + (lane & 31u);
             if (q < nq) {
                 const float a2 = 2.0f * q_norm[q];
-                cq[ni] = I8 ? a2 * q_scale[q] / i8_scale : a2;
+                cq[ni] = I8 ? a2 * q_scale[q] : a2;
                 ce[ni] = I8 ? a2 * q_eps[q] : q_eps[q];
             }
         }
@@ -508,9 +573,16 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                     const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
                     bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
                     bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
-                } else if (I8) { // 1 / (scale ||x||) of the 4 rows (padded to the tile, 0 beyond n_rows)
+                }
+                float rf[4] = {0.f, 0.f, 0.f, 0.f}; // int8: S * inv_rn = the cosine up to the query's scale s_q
+                if (I8) {                           // (padded to the tile, 0 beyond n_rows)
                     const float4 p = *(const float4 *)(inv_rn + row4);
-                    bn[0] = p.x, bn[1] = p.y, bn[2] = p.z, bn[3] = p.w;
+                    rf[0] = p.x, rf[1] = p.y, rf[2] = p.z, rf[3] = p.w;
+                    if (MODE == 1) { // q.x = a ||x|| cos: the row's factor becomes ||x|| inv_rn
+#pragma unroll
+                        for (int rl = 0; rl < 4; ++rl)
+                            rf[rl] *= bn[rl];
+                    }
                 }
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
@@ -528,10 +600,10 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                         }
 #endif
                         float v = (float)acc[mi][ni][r];
-                        if (I8 && MODE == 1) // upper bound of V = 2 q.x - ||x||^2: 2a (s_q S / scale + eps_q ||x||) - ||x||^2 (1 - gamma)
-                            v = __builtin_fmaf(v, cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
-                        else if (I8) // S / (scale ||x||): the cosine up to the query's scale s_q (mfma_rescore_kernel applies it)
-                            v = v * bn[rl];
+                        if (I8 && MODE == 1) // upper bound of V = 2 q.x - ||x||^2: 2a ||x|| (s_q S inv_rn + eps_q) - ||x||^2 (1 - gamma)
+                            v = __builtin_fmaf(v * rf[rl], cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
+                        else if (I8) // S inv_rn: the cosine up to the query's scale s_q (mfma_rescore_kernel applies it)
+                            v = v * rf[rl];
                         else if (MODE == 1)
                             v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
                         float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
@@ -713,7 +785,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                                                                     const float *__restrict__ q_norm,
                                                                     const float *__restrict__ q_eps, uint32_t a_chunks,
                                                                     uint64_t a_bytes, const float *__restrict__ inv_rn,
-                                                                    const float *__restrict__ q_scale, float i8_scale)
+                                                                    const float *__restrict__ q_scale)
 {
     constexpr uint32_t KU = 4u, TROWS = 256u;
     // NCOL = 64-query columns per workgroup (1: <= 64 queries, 2: <= 128): 32 row units + 8 NCOL query units of
@@ -804,7 +876,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
             const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
             if (q < nq) { // as in mfma_prefilter256_kernel
                 const float a2 = 2.0f * q_norm[q];
-                cq[ni] = I8 ? a2 * q_scale[q] / i8_scale : a2;
+                cq[ni] = I8 ? a2 * q_scale[q] : a2;
                 ce[ni] = I8 ? a2 * q_eps[q] : q_eps[q];
             }
         }
@@ -825,9 +897,16 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                 const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
                 bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
                 bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
-            } else if (I8) {
+            }
+            float rf[4] = {0.f, 0.f, 0.f, 0.f}; // as in mfma_prefilter256_kernel
+            if (I8) {
                 const float4 p = *(const float4 *)(inv_rn + row4);
-                bn[0] = p.x, bn[1] = p.y, bn[2] = p.z, bn[3] = p.w;
+                rf[0] = p.x, rf[1] = p.y, rf[2] = p.z, rf[3] = p.w;
+                if (MODE == 1) {
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl)
+                        rf[rl] *= bn[rl];
+                }
             }
 #pragma unroll
             for (int rl = 0; rl < 4; ++rl) {
@@ -837,9 +916,9 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
                 for (int ni = 0; ni < NI; ++ni) {
                     float v = (float)acc[ni][r];
                     if (I8 && MODE == 1)
-                        v = __builtin_fmaf(v, cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
+                        v = __builtin_fmaf(v * rf[rl], cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
                     else if (I8)
-                        v = v * bn[rl];
+                        v = v * rf[rl];
                     else if (MODE == 1)
                         v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
                     float sp = __uint_as_float((__float_as_uint(v) & keep_mask) | idx);
@@ -1256,10 +1335,20 @@ hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, ui
 }
 
 hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
-                                     int *q_bad, float *q_norm, float *q_eps, float *q_scale, hipStream_t s)
+                                     int *q_bad, float *q_norm, float *q_eps, float *q_scale, const uint32_t *stats,
+                                     hipStream_t s)
 {
     hipLaunchKernelGGL(mfma_query_prep_i8_kernel, dim3(nq), dim3(64), 0, s, d_queries, nq, dim, (int8_t *)q_mirror, KS,
-                       q_bad, q_norm, q_eps, q_scale, mfma_f32_slack(KS * 32u));
+                       q_bad, q_norm, q_eps, q_scale, stats, mfma_f32_slack(KS * 32u));
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma_mirror_i8(const uint4 *corpus, const float *row_norms, uint4 *mirror, float *inv_rn,
+                                 uint32_t n_rows, uint32_t d_chunks, uint32_t d_chunks8, uint32_t k_pad,
+                                 uint32_t *stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_mirror_i8_kernel, dim3((n_rows + 255u) / 256u), dim3(256), 0, s, corpus, row_norms, mirror,
+                       inv_rn, n_rows, d_chunks, d_chunks8, k_pad, stats);
     return hipGetLastError();
 }
 
@@ -1299,7 +1388,7 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 #define VFSX_SKINNY(MODE, NCOL)                                                                                    \
     hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, false>), dim3(g.n_strips), dim3(512), 0, s,    \
                        mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists, g.strip_tiles, rn, q_norm,      \
-                       q_eps, 0u, (uint64_t)0, (const float *)nullptr, (const float *)nullptr, 1.0f)
+                       q_eps, 0u, (uint64_t)0, (const float *)nullptr, (const float *)nullptr)
         if (nq <= 64u) {
             if (euclid)
                 VFSX_SKINNY(1, 1);
@@ -1317,7 +1406,7 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 #define VFSX_PF256(MODE)                                                                                           \
     hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, false>), grid, dim3(512), 0, s,  \
                        mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn,    \
-                       q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr, (const float *)nullptr, 1.0f, qpx,   \
+                       q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr, (const float *)nullptr, qpx,         \
                        g.n_strips)
     if (euclid)
         VFSX_PF256(1);
@@ -1332,7 +1421,7 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint64_t corpus_bytes, const void *q_mirror,
                                     float *cand, uint32_t n_rows, const MfmaGeometry &g, uint32_t nq, int euclid,
                                     const float *rn2, const float *inv_rn, const float *q_norm, const float *q_eps,
-                                    const float *q_scale, float i8_scale, hipStream_t s)
+                                    const float *q_scale, hipStream_t s)
 {
     const uint32_t n_qtiles = (nq + 255u) / 256u;
     uint32_t qpx = 1;
@@ -1342,8 +1431,7 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
 #define VFSX_SKINNY(MODE, NCOL)                                                                                    \
     hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, true>), dim3(g.n_strips), dim3(512), 0, s,     \
                        corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists,            \
-                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale,  \
-                       i8_scale)
+                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale)
         if (nq <= 64u) {
             if (euclid)
                 VFSX_SKINNY(1, 1);
@@ -1362,7 +1450,7 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
     hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, true>), grid, dim3(512), 0, s,   \
                        corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,  \
                        g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale,  \
-                       i8_scale, qpx, g.n_strips)
+                       qpx, g.n_strips)
     if (euclid)
         VFSX_PF256(1);
     else

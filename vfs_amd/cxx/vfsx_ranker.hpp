@@ -77,7 +77,16 @@ public:
     // this shard's first global scan position (row-sharded stores)
     void set_row_base(uint64_t row_base) { check(vfsx_corpus_set_row_base(h_, row_base)); }
     // many-query batches on the matrix cores (no reference counterpart; results unchanged)
-    void enable_mfma(bool on = true) { check(vfsx_corpus_enable_mfma(h_, on ? 1 : 0)); }
+    // kind: 0 off, 1 bf16 mirror, 2 int8 mirror of an f32 store, 3 the int8 store itself
+    std::pair<int, float> mfma_mirror()
+    {
+        int kind = 0;
+        float res = 0.0f;
+        check(vfsx_corpus_mfma_mirror(h_, &kind, &res));
+        return {kind, res};
+    }
+    // mirror (f32 stores): 1 auto, 2 bf16, 3 int8 with a scale per row (include/vfsx.h)
+    void enable_mfma(bool on = true, int mirror = 1) { check(vfsx_corpus_enable_mfma(h_, on ? mirror : 0)); }
 
     // nq queries at once ("A2/A3 + A4 per query", SURVEY.md 8a batch note): flat [nq][k] outputs
     struct Batch {

@@ -201,9 +201,19 @@ class Corpus:
         _lib.check(self._lib.vfsx_search_device_noalloc(self._h, C.c_void_p(d_queries_ptr), nq, k, int(metric),
                                                         C.c_void_p(d_hits_ptr), C.c_void_p(stream_ptr)))
 
-    def enable_mfma(self, enabled: bool = True) -> None:
-        """Build (or drop) the bf16 mirror that lets large Cosine batches run on the matrix cores."""
-        _lib.check(self._lib.vfsx_corpus_enable_mfma(self._h, 1 if enabled else 0))
+    def enable_mfma(self, enabled: bool = True, mirror: str = "auto") -> None:
+        """Let Cosine / Euclidean batches run on the matrix cores (results stay those of the exact scan).  f32 stores
+        get a mirror: "int8" (1 B / element, per-row scales), "bf16" (2 B / element) or "auto" (int8 unless the rows'
+        measured quantization residual or a batch's fallbacks say bf16).  int8 stores need none."""
+        mode = {"auto": 1, "bf16": 2, "int8": 3}[mirror]
+        _lib.check(self._lib.vfsx_corpus_enable_mfma(self._h, mode if enabled else 0))
+
+    def mfma_mirror(self) -> Tuple[str, float]:
+        """(what the matrix-core path multiplies: "off" | "bf16" | "int8" | "int8-store", the rows' largest measured
+        rounding / quantization residual)."""
+        kind, res = C.c_int(0), C.c_float(0.0)
+        _lib.check(self._lib.vfsx_corpus_mfma_mirror(self._h, C.byref(kind), C.byref(res)))
+        return ("off", "bf16", "int8", "int8-store")[kind.value], float(res.value)
 
     def mfma_stats(self, reset: bool = False) -> Tuple[int, int]:
         q, f = C.c_uint64(0), C.c_uint64(0)
