@@ -1547,6 +1547,19 @@ MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8)
 // mfma_f32_slack = (6K + 64) u + 2^-20 (the last term: bf16 subnormals the MFMA may flush, < K 2^-126, and the
 // f32 roundings of eps_q's own evaluation).  The Euclidean path needs only (2) of it, 2.03 K u; the surplus
 // (>= 3.9 K u) is what covers the three f32 roundings of its epilogue, 3 u |2ab (s~ + eps_q)| <= 3.1 u (2ab).
+//
+// int8 operands (v_mfma_i32_32x32x32_i8): x~ = s_x X, q~ = s_q Q with int8 vectors X, Q; S = X.Q is EXACT in int32
+// (|S| <= 128 * 127 * 32768 < 2^31), so (2) vanishes and only the quantization residuals remain:
+//   int8 store:   X = the stored bytes, s_x = 1 / (scale b) exactly the row (x^ = s_x X up to the f32 rounding of the
+//                 stored value byte / scale, vector.rs:138, <= u per element): r_x = 0,
+//                 |s_q s_x S - s^| = |x^.(q~ - q^)| <= ||x^|| r_q = r_q (1 + |e_b|)
+//   int8 mirror:  X = round(x^ / s_x), r_x measured per row by mfma_mirror_i8_kernel, R_x its maximum:
+//                 |s_x s_q S - s^| <= r_x ||q~|| + ||x^|| r_q <= R_x (1 + r_q + |e_a|) + (1 + |e_b|) r_q
+//   => eps_q = (R_x + r_q)(1 + 2^-7) + R_x r_q + mfma_f32_slack(K)   (mfma_query_prep_i8_kernel; R_x = 0 for a store)
+// r_q, r_x carry + 2^-22 for the f32 roundings inside their own measurement (d = y - s t: two roundings of <= u |y|).
+// The epilogue's f32 operations on the score -- int32 -> f32 conversion of S (relative u), the product with the
+// row factor inv_rn (and ||x||, Euclidean), the query factor -- are 3-4 relative roundings of a value <= ~1 in
+// cosine units, inside the same surplus of mfma_f32_slack that covers the bf16 epilogue.  (3) and (4) are unchanged.
 float mfma_f32_slack(uint32_t k_pad)
 {
     return (6.0f * (float)k_pad + 64.0f) * 0x1p-24f + 0x1p-20f;
