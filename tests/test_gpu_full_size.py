@@ -126,22 +126,59 @@ def test_c4_10m_x1024_mfma_batch_equals_exact_scan(oracle):
     c = vfs_amd.Corpus(d, capacity_rows=n)
     c.fill_synthetic(SEED_C, n)
     queries = oracle.synth_f32(SEED_Q, 0, nq, d)
+    sample = [0, 1, 777, 2048, 4095, 3, 4, 5]
+    for metric in (1, 0):
+        c.enable_mfma(False)
+        ids_e, dist_e, _ = c.search_batch(queries[sample], k, metric)
+        per_mirror = {}
+        for mirror in ("int8", "bf16"):  # both mirrors an f32 store can have (the library's choice here: int8)
+            c.enable_mfma(True, mirror=mirror)
+            assert c.mfma_mirror()[0] == mirror
+            c.mfma_stats(reset=True)
+            ids_m, dist_m, cnt_m = c.search_batch(queries, k, metric)
+            mq, fb = c.mfma_stats()
+            assert mq == nq and fb < nq // 10
+            assert (ids_m[sample] == ids_e).all()
+            assert (bits(dist_m[sample]) == bits(dist_e)).all()
+            assert (cnt_m == k).all() and (np.diff(dist_m, axis=1) >= 0).all()
+            per_mirror[mirror] = (ids_m, dist_m)
+        # all 4096 queries: the two prefilters (different operands, different bounds) agree bit for bit
+        assert (per_mirror["int8"][0] == per_mirror["bf16"][0]).all()
+        assert (bits(per_mirror["int8"][1]) == bits(per_mirror["bf16"][1])).all()
+        # the winner of query 0: regenerate that row on the host and check the oracle's distance
+        row = int(ids_m[0, 0]) - 1
+        x = oracle.synth_f32(SEED_C, row, 1, d)
+        assert bits(oracle.all_distances(x, queries[0], metric))[0] == bits(dist_m[0, :1])[0]
+    c.enable_mfma(True)
+    assert c.mfma_mirror()[0] == "int8"  # auto on this corpus
+    c.close()
+
+
+def test_c4_10m_x1024_int8_store_mfma_batch_equals_exact_scan(oracle):
+    """C4's shape on an int8 store (10 GB): the int8 MFMA prefilter reads the rb64 corpus itself.  Sampled queries of
+    a 4096-query batch equal the exact scan, Cosine and Euclidean; a winner's distance equals the oracle's on the
+    regenerated row."""
+    import vfs_amd
+    n, d, nq, k = 10_000_000, 1024, 4096, 10
+    c = vfs_amd.Corpus(d, quantize=True, capacity_rows=n)
+    c.fill_synthetic(SEED_C, n)
+    queries = oracle.synth_f32(SEED_Q, 0, nq, d)
+    sample = [0, 1, 777, 2048, 4095, 3, 4, 5]
     for metric in (1, 0):
         c.enable_mfma(True)
+        assert c.mfma_mirror() == ("int8-store", 0.0)
         c.mfma_stats(reset=True)
         ids_m, dist_m, cnt_m = c.search_batch(queries, k, metric)
         mq, fb = c.mfma_stats()
         assert mq == nq and fb < nq // 10
         c.enable_mfma(False)
-        sample = [0, 1, 777, 2048, 4095, 3, 4, 5]
         ids_e, dist_e, _ = c.search_batch(queries[sample], k, metric)
         assert (ids_m[sample] == ids_e).all()
         assert (bits(dist_m[sample]) == bits(dist_e)).all()
         assert (cnt_m == k).all() and (np.diff(dist_m, axis=1) >= 0).all()
-        # the winner of query 0: regenerate that row on the host and check the oracle's distance
         row = int(ids_m[0, 0]) - 1
-        x = oracle.synth_f32(SEED_C, row, 1, d)
-        assert bits(oracle.all_distances(x, queries[0], metric))[0] == bits(dist_m[0, :1])[0]
+        x = oracle.synth_i8(SEED_C, row, 1, d)
+        assert bits(oracle.all_distances(x, queries[0], metric, scale=127.0))[0] == bits(dist_m[0, :1])[0]
     c.close()
 
 
