@@ -251,6 +251,28 @@ def main(argv=None) -> int:
         elapsed = float(t.item())
     dbg("max over ranks done")
 
+    # N > 1: the same steps without the exchange (every rank scans its shard, nobody merges): the rate one shard
+    # alone sustains in THIS run.  value / that = what the collective + merge + rank skew cost, i.e. the weak-scaling
+    # efficiency of the query path (ideal: value stays at the one-shard rate while the corpus grows N-fold).
+    local_only_qps = None
+    if world > 1:
+        def local_step(step_idx: int) -> None:
+            stream = torch.cuda.current_stream().cuda_stream
+            base = step_idx * qps_step
+            if args.mode == "batch":
+                corpus.search_device(d_q[base].data_ptr(), qps_step, k, metric, d_local.data_ptr(), stream)
+            else:
+                for j in range(qps_step):
+                    corpus.search_device(d_q[base + j].data_ptr(), 1, k, metric, d_local[j].data_ptr(), stream)
+        fence()
+        t1 = time.perf_counter()
+        for s_i in range(args.steps):
+            local_step(args.warmup + s_i)
+        fence()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        local_only_qps = args.steps * qps_step / float(t.item())
+
     # roofline leg: same launches, scan kernel bracketed by HIP events on its own stream
     roof_steps = min(args.steps, 4)
     corpus.set_profiling(True)
@@ -334,6 +356,9 @@ def main(argv=None) -> int:
     if world > 1:
         out["scaling_note"] = ("rows_per_gpu is fixed, so the corpus grows with N: ideal weak scaling is a constant "
                                "value (queries/s against the whole corpus) and N x hbm_gbps_aggregate")
+        out["one_shard_rate_in_this_run"] = {"value": round(local_only_qps, 3), "unit": "queries/s",
+                                             "what": "the same steps with no exchange (slowest rank): the ideal for value"}
+        out["weak_scaling_efficiency_vs_one_shard"] = round(qps_global / local_only_qps, 4)
         out["rccl_ranks"] = (int(vfs_amd.load().vfsx_comm_world(comm.handle)) if comm is not None else
                              (dist.get_world_size() if dist.get_backend() == "nccl" else None))
         out["collective"] = ("vfsx_comm_merge_hits: ncclAllGather (RCCL) + device merge, one per step" if comm is not None

@@ -824,9 +824,19 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         uint32_t flagged = 0;
         for (uint32_t q = 0; q < nq; ++q)
             flagged += c->h_flags[q] ? 1u : 0u;
+        bool to_bf16 = false;
         if (mirror_is_i8(c) && c->mirror_pref == 0 && flagged * 8u > nq) {
-            // auto: the int8 mirror's wider margin sends too many of this data's queries back: bf16 mirror from the
-            // next batch on (rebuilt by ensure_mirror), for good
+            // auto: does the int8 mirror's wider margin send too many of this data's queries back?  (Queries the
+            // path never took -- zero / out-of-range norms -- are flagged too and say nothing about the mirror.)
+            std::vector<int> bad(nq);
+            HIP_CHECK(hipMemcpyAsync(bad.data(), c->q_bad.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            uint32_t by_margin = 0;
+            for (uint32_t q = 0; q < nq; ++q)
+                by_margin += (c->h_flags[q] && !bad[q]) ? 1u : 0u;
+            to_bf16 = by_margin * 8u > nq;
+        }
+        if (to_bf16) { // bf16 mirror from the next batch on (rebuilt by ensure_mirror), for good
             c->mirror_kind = vfsx_corpus::kMirrorBf16;
             c->mirror_rows = 0;
             c->mirror_bytes = 0;
