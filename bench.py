@@ -47,21 +47,21 @@ WORKLOADS = {
                                            "own Simd path accepts, rank.rs:303)"),
     "c5": (12_500_000, 768, False, 0, 32, "C5 shard 12.5Mx768 f32 Euclidean per GPU (100Mx768 over 8 GPUs), "
                                           "single-query scan, RCCL all-gather top-k merge"),
-    "c4e": (10_000_000, 1024, False, 0, 4096, "4096-query batch x 10Mx1024 f32 Euclidean as Q.X^T on MFMA (the library's "
-                                              "choice of mirror) + per-row upper-bound epilogue + fused top-k, exact f32 "
-                                              "re-score (extension of C4 to the Euclidean metric)"),
-    "c4": (10_000_000, 1024, False, 1, 4096, "C4 4096-query batch x 10Mx1024 f32 Cosine as Q.X^T on MFMA (the library's "
-                                             "choice of mirror: int8 with per-row scales unless the data says bf16) + "
-                                             "fused top-k, exact f32 re-score"),
-    "c4bf16": (10_000_000, 1024, False, 1, 4096, "C4 with the bf16 mirror forced: Q.X^T on bf16 MFMA + fused top-k, exact "
-                                                 "f32 re-score"),
-    "c4ebf16": (10_000_000, 1024, False, 0, 4096, "C4 Euclidean with the bf16 mirror forced"),
+    "c4": (10_000_000, 1024, False, 1, 4096, "C4 4096-query batch x 10Mx1024 f32 Cosine as Q.X^T on bf16 MFMA (bf16 mirror, "
+                                             "the operand BASELINE config 4 names) + fused top-k, exact f32 re-score"),
+    "c4e": (10_000_000, 1024, False, 0, 4096, "4096-query batch x 10Mx1024 f32 Euclidean as Q.X^T on bf16 MFMA + per-row "
+                                              "upper-bound epilogue + fused top-k, exact f32 re-score (extension of C4 to "
+                                              "the Euclidean metric)"),
+    "c4auto": (10_000_000, 1024, False, 1, 4096, "C4 with the operand the library picks by itself for an f32 store: an int8 "
+                                                 "mirror with per-row scales on int8 MFMA unless the data says bf16; same "
+                                                 "exact results"),
+    "c4eauto": (10_000_000, 1024, False, 0, 4096, "C4 Euclidean with the library's own choice of operand (int8 mirror)"),
     "c4i8": (10_000_000, 1024, True, 1, 4096, "4096-query batch x 10Mx1024 int8 QuantizedVector Cosine: int8 MFMA over the "
                                               "rb64 corpus itself (no mirror) + fused top-k, exact f32 re-score"),
     "c3b": (10_000_000, 128, True, 0, 4096, "C3 in batches: 4096 queries x 10Mx128 int8 QuantizedVector Euclidean, int8 "
                                             "MFMA over the rb64 corpus + upper-bound epilogue, exact f32 re-score"),
 }
-MFMA_WORKLOADS = ("c4", "c4e", "c4bf16", "c4ebf16", "c4i8", "c3b")
+MFMA_WORKLOADS = ("c4", "c4e", "c4auto", "c4eauto", "c4i8", "c3b")
 METRIC_NAMES = ["euclidean", "cosine", "simd_euclidean", "simd_cosine", "euclidean_i8_domain"]
 
 
@@ -203,7 +203,7 @@ def main(argv=None) -> int:
     corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
     corpus.set_row_base(rank * rows)
     if mfma:
-        corpus.enable_mfma(True, mirror="bf16" if workload.endswith("bf16") else "auto")
+        corpus.enable_mfma(True, mirror="bf16" if workload in ("c4", "c4e") else "auto")
         mirror_kind, mirror_rx = corpus.mfma_mirror()
 
     dbg("corpus filled")

@@ -16,7 +16,7 @@ run c1d64 300 --workload c1d64 --steps 10 --warmup 2 &&
 run c4 400 --workload c4 --no-cpu-baseline &&
 run c4e 400 --workload c4e --no-cpu-baseline &&
 run c4i8 400 --workload c4i8 --no-cpu-baseline &&
-run c4bf16 400 --workload c4bf16 --no-cpu-baseline &&
-run c4ebf16 400 --workload c4ebf16 --no-cpu-baseline &&
+run c4auto 400 --workload c4auto --no-cpu-baseline &&
+run c4eauto 400 --workload c4eauto --no-cpu-baseline &&
 run c3b 400 --workload c3b --no-cpu-baseline &&
 VFSX_BENCH_BACKEND=gloo run g2_gloo 400 --gpus 2 --workload c2 --steps 5 --warmup 1

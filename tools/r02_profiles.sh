@@ -17,4 +17,4 @@ QPS=8 prof c5 --workload c5 --steps 4 --warmup 1 &&
 QPS=4096 prof c4 --workload c4 --steps 5 --warmup 1 &&
 QPS=4096 prof c4e --workload c4e --steps 5 --warmup 1 &&
 QPS=4096 prof c4i8 --workload c4i8 --steps 5 --warmup 1 &&
-QPS=4096 prof c4bf16 --workload c4bf16 --steps 5 --warmup 1
+QPS=4096 prof c4auto --workload c4auto --steps 5 --warmup 1
