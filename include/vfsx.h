@@ -337,7 +337,7 @@ int vfsx_comm_merge_hits(vfsx_comm *comm, const vfsx_hit *d_local, uint32_t nq, 
  * and moves to bf16 for good when the rows' measured quantization residual is large or a batch sends more than 1/8 of
  * its queries back.  An int8 store needs no mirror: its rb64 rows are the int8 operand (+12 bytes per row).
  * Afterwards vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 queries with
- * k <= 64 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the
+ * k <= 128 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the
  * exact scan) through Q.X^T on MFMA + an exact sequential re-score of the surviving candidates + a bound check built
  * from the measured rounding / quantization residuals, and re-run the exact scan for any query the check cannot
  * clear: the results stay bit-identical to the single-query scan.  On this path vfsx_search_device synchronises

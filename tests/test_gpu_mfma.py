@@ -479,3 +479,38 @@ def test_mfma_mirror_choice_and_auto_policy(oracle, monkeypatch):
         assert c.mfma_mirror()[0] == "bf16"
     same_as_exact(c, qd)
     c.close()
+
+
+@pytest.mark.parametrize("k", [65, 100, 128])
+@pytest.mark.parametrize("quantize", [False, True])
+def test_mfma_result_limits_up_to_128(oracle, quantize, k, mirror_kind):
+    """The reference's own benchmark asks for result_limit = 100: batches with 64 < k <= 128 stay on the matrix cores
+    (256 candidates per query, two-register top-k in the re-score); k = 129 takes the exact scan.  (A forced int8
+    mirror's margin holds more than 256 rows for most queries at k = 100 on this small corpus: they are re-run by the
+    exact scan -- which is why the library's own choice moves such data to the bf16 mirror.)"""
+    import vfs_amd
+    rng = np.random.default_rng(900 + k)
+    n, d = 400_000, 64  # (enough candidate lists that three rows above the margin rarely share one)
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (40, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    (c.append_f32 if quantize else c.append)(rows)
+    ref = oracle.quantize(rows, 127.0) if quantize else rows
+    for metric in (1, 0):
+        c.enable_mfma(True)
+        c.mfma_stats(reset=True)
+        ids_m, dist_m, cnt_m = c.search_batch(queries, k, metric)
+        mq, fb = c.mfma_stats()
+        assert mq == len(queries)
+        if quantize or mirror_kind == "bf16":
+            assert fb <= len(queries) // 2
+        c.enable_mfma(False)
+        ids_e, dist_e, cnt_e = c.search_batch(queries, k, metric)
+        assert (cnt_m == cnt_e).all() and (ids_m == ids_e).all() and (bits(dist_m) == bits(dist_e)).all()
+        oi, od, _ = oracle.topk_scan(ref, queries[7], metric, k)
+        assert (ids_m[7] == oi).all() and (bits(dist_m[7]) == bits(od)).all()
+    c.enable_mfma(True)
+    c.mfma_stats(reset=True)
+    c.search_batch(queries, 129, 1)
+    assert c.mfma_stats()[0] == 0
+    c.close()

@@ -905,7 +905,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     chain_search_stream(c, s);
     // the reference's four metrics; the integer-domain extension has its own kernel
     const bool metric_ok = metric != VFSX_EUCLIDEAN_I8DOMAIN;
-    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= 64 && c->dim <= vfsx::kMfmaMaxDim &&
+    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= vfsx::kMfmaMaxK && c->dim <= vfsx::kMfmaMaxDim &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok && c->mfma_backoff > 0) {
         --c->mfma_backoff; // see vfsx_corpus::mfma_backoff

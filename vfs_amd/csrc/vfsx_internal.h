@@ -105,6 +105,7 @@ struct MfmaGeometry {
     size_t mirror_bytes; // bf16 mirror of the corpus (rows padded to 256); 0 for int8 stores (rb64 is the operand)
 };
 constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor assumes K <= 32768
+constexpr uint32_t kMfmaMaxK = 128; // result_limit the matrix-core batch path serves (256 candidates re-scored per query)
 MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8);
 float mfma_f32_slack(uint32_t k_pad);
 

@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x;
-    const uint32_t list_stride = k > 64u ? k : 64u;
+    const uint32_t list_stride = k > 64u ? 128u : 64u; // (WaveTopKReg2 publishes 128 entries)
     if (DTYPE == VFSX_I8) {
         for (uint32_t i = threadIdx.x; i < 256u * 32u; i += kBlock)
             lut_s[i] = lut[i >> 5];
@@ -1189,10 +1189,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
 
     uint64_t *mine = dyn_lds + wave * list_stride;
     __syncthreads();
-    if (TopK::kInRegisters) {
-        mine[lane] = kSentinel;
-        top.store(mine);
-    }
+    top.spill(mine); // (kSentinel padded to 64 / 128 entries; a no-op for a list that lives in LDS)
     __syncthreads();
     if (wave == 0) {
         for (int w = 1; w < kWavesPerBlock; ++w) {
@@ -1479,13 +1476,21 @@ hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uin
 
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s)
 {
-    const uint32_t list_stride = a.k > 64u ? a.k : 64u;
+    const uint32_t list_stride = a.k > 64u ? 128u : 64u;
     const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
+    // k <= 64: one register per lane; k <= 128 (kMfmaMaxK): two
+#define VFSX_RESCORE_T(DT, M, TOPK)                                                                                  \
+    hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, TOPK>), dim3(nq), dim3(kBlock), lds, s, a.corpus, a.row_norms,     \
+                       a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks, a.q_stride,     \
+                       a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma, a.only_flagged,   \
+                       a.q_scale)
 #define VFSX_RESCORE(DT, M)                                                                                          \
-    hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, WaveTopKReg>), dim3(nq), dim3(kBlock), lds, s, a.corpus,           \
-                       a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks,    \
-                       a.q_stride, a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma,       \
-                       a.only_flagged, a.q_scale)
+    do {                                                                                                             \
+        if (a.k <= kMaxRegisterK)                                                                                    \
+            VFSX_RESCORE_T(DT, M, WaveTopKReg);                                                                      \
+        else                                                                                                         \
+            VFSX_RESCORE_T(DT, M, WaveTopKReg2);                                                                     \
+    } while (0)
     if (dtype == VFSX_I8) {
         if (a.euclid)
             VFSX_RESCORE(VFSX_I8, VFSX_EUCLIDEAN);
@@ -1498,6 +1503,7 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
             VFSX_RESCORE(VFSX_F32, VFSX_COSINE);
     }
 #undef VFSX_RESCORE
+#undef VFSX_RESCORE_T
     return hipGetLastError();
 }
 
