@@ -96,8 +96,9 @@ hipError_t launch_scan_i8dom(const ScanArgs &a, uint32_t nq, uint32_t grid_x, bo
 
 // ---- many-query batches on the matrix cores (vfsx_mfma.hip) ---------------------------------
 struct MfmaGeometry {
-    uint32_t k_pad;      // dim rounded up to the ring round: 128 (bf16 mirror) or 256 (int8 stores)
+    uint32_t k_pad;      // dim rounded up to 128
     uint32_t KS;         // fragment k-slices: k_pad / 16 (bf16) or k_pad / 32 (int8)
+    uint32_t ku;         // k-slices per K-step of the 256 x 256 kernel: 4, or 2 when an int8 K is an odd multiple of 128
     uint32_t n_rowtiles; // ceil(n_rows / 256)
     uint32_t strip_tiles; // row tiles per strip (1..16)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)

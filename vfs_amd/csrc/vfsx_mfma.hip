@@ -1443,15 +1443,24 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
 #undef VFSX_SKINNY
         return hipGetLastError();
     }
-#define VFSX_PF256(MODE)                                                                                           \
-    hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, true>), grid, dim3(512), 0, s,   \
-                       corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,  \
+    // g.ku == 2: K is an odd number of 128-k half-steps (dim <= 128, 257..384, ...): the 64-k K-step variant takes
+    // it without padding it to the next 256 (at dim 128 that padding would double the kernel's MFMA and fill work)
+#define VFSX_PF256(KU, NS, MODE)                                                                                   \
+    hipLaunchKernelGGL((mfma_prefilter256_kernel<KU, NS, MODE, true>), grid, dim3(512), 0, s, corpus,               \
+                       (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,          \
                        g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale,  \
                        qpx, g.n_strips)
-    if (euclid)
-        VFSX_PF256(1);
-    else
-        VFSX_PF256(0);
+    if (g.ku == 2u) {
+        if (euclid)
+            VFSX_PF256(2, 2, 1);
+        else
+            VFSX_PF256(2, 2, 0);
+    } else {
+        if (euclid)
+            VFSX_PF256(VFSX_PF_KU, VFSX_PF_NSTAGE, 1);
+        else
+            VFSX_PF256(VFSX_PF_KU, VFSX_PF_NSTAGE, 0);
+    }
 #undef VFSX_PF256
     return hipGetLastError();
 }
@@ -1510,10 +1519,12 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
 MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8)
 {
     MfmaGeometry g;
-    // whole ring rounds only: K-steps (of 4 MFMA k-slices: 64 bf16 / 128 int8 k) per tile % ring depth (2) == 0
-    const uint32_t k_round = int8 ? 256u : 128u;
-    g.k_pad = (dim + k_round - 1u) / k_round * k_round;
+    // whole ring rounds only: K-steps (of 4 MFMA k-slices: 64 bf16 / 128 int8 k) per tile % ring depth (2) == 0, i.e.
+    // K a multiple of 128 (bf16) or 256 (int8); the int8 kernel also exists with K-steps of 2 k-slices (ku = 2), which
+    // takes the multiples of 128 in between
+    g.k_pad = (dim + 127u) / 128u * 128u;
     g.KS = g.k_pad / (int8 ? 32u : 16u);
+    g.ku = (int8 && g.KS % 8u != 0u) ? 2u : 4u;
     g.n_rowtiles = (n_rows + 255u) / 256u;
     // aim for >= ~4096 candidate lists per query so that three rows above the safety margin rarely share
     // one (small corpora get short strips -- and more workgroups); a list holds at most 1024 rows (10 index
