@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void scan_i8dom_kernel(const uint4 *__restr
     extern __shared__ __align__(16) uint64_t dyn_lds[];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t list_stride = k > 64u ? k : 64u;
+    const uint32_t list_stride = topk_list_stride(k);
     const uint32_t *__restrict__ qw = qwords + (size_t)blockIdx.y * qw_stride; // wave-uniform: s_load
     const int QQ = (int)qw[d_chunks * 4u];
 
@@ -122,10 +122,7 @@ __global__ __launch_bounds__(kBlock) void scan_i8dom_kernel(const uint4 *__restr
     // fold the 4 waves' lists into wave 0's, one list per workgroup to HBM ([q][j][list])
     __syncthreads();
     uint64_t *mine = dyn_lds + (size_t)wave * list_stride;
-    if (TopK::kInRegisters) {
-        mine[lane] = kSentinel;
-        top.store(mine);
-    }
+    top.spill(mine);
     __syncthreads();
     if (wave == 0) {
         for (int w = 1; w < kWavesPerBlock; ++w) {

@@ -21,6 +21,12 @@ constexpr uint32_t kRowBlock = 64;
 constexpr uint32_t kChunkBytes = 16;
 constexpr uint64_t kSentinel = ~0ull;   // empty top-k slot
 constexpr uint32_t kMaxRegisterK = 64;  // k <= 64: the wave's list lives in registers
+constexpr uint32_t kMaxRegister2K = 128; // k <= 128: two registers per lane (WaveTopKReg2)
+// u64 entries one wave's published list occupies in LDS: what its top-k class spills (64 / 128) or k itself
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t topk_list_stride(uint32_t k) { return k <= kMaxRegisterK ? 64u : (k <= kMaxRegister2K ? 128u : k); }
 
 inline uint32_t elems_per_chunk(int dtype) { return dtype == VFSX_I8 ? 16u : 4u; }
 
