@@ -191,3 +191,35 @@ def test_result_limit_beyond_one_pass(oracle, quantize):
                 assert (ids[qi, :cnt[qi]] == oi).all()
                 assert (_bits(dist[qi, :cnt[qi]]) == _bits(od)).all()
     c.close()
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_long_results_radix_select(oracle, quantize):
+    """result_limit > 128 leaves the per-wave lists: the scan writes every row's composite key and an 8-pass radix
+    select + one-workgroup sort emits the hits in chunks of 4096 from a moving cursor.  Batches of queries (they share
+    corpus passes), chunk boundaries (4096, 4097, 8192), k beyond the rows, explicit ids, NaN / duplicate / tied
+    distances -- all equal to the oracle's stable ranking."""
+    import vfs_amd
+    rng = np.random.default_rng(77 + quantize)
+    n, d = 20011, 20
+    if quantize:
+        base = rng.uniform(-6, 6, (300, d)).round(3).astype(np.float32)
+        rows = oracle.quantize(base[rng.integers(0, 300, n)], 127.0)  # 300 distinct rows: ties everywhere
+        kw = {"scale": 127.0}
+    else:
+        rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+        rows[100:140] = rows[50]  # duplicates
+        kw = {}
+    ids = rng.permutation(np.arange(5, 5 + n)).astype(np.uint64)
+    queries = rng.uniform(-1, 1, (11, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    c.append(rows, ids=ids)
+    for k in (129, 1000, 4096, 4097, 8192, n, n + 500):
+        for metric in (0, 1):
+            gi, gd, gc = c.search_batch(queries, k, metric)
+            for qi in (0, 5, 10):
+                oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k, ids=ids, **kw)
+                assert gc[qi] == len(oi) == min(k, n)
+                assert (gi[qi, :gc[qi]] == oi).all(), (k, metric, qi)
+                assert (_bits(gd[qi, :gc[qi]]) == _bits(od)).all(), (k, metric, qi)
+    c.close()

@@ -180,6 +180,8 @@ struct vfsx_corpus {
     float *d_inv_rn = nullptr;   // int8 stores: [same rows] 1 / (scale b); the rb64 corpus is the MFMA operand, no mirror
     size_t rn2_rows = 0;
     DeviceBuf<float> q_norm, q_eps, q_scale;
+    DeviceBuf<uint32_t> long_state, long_hist; // result_limit > kLongResultK: radix-select state / histograms
+    DeviceBuf<uint64_t> long_sel;              // ... and the compacted keys of one chunk per query
     DeviceBuf<uint32_t> fb_idx;  // exact fallback of flagged queries: their indices, compacted copies, hits
     DeviceBuf<float> fb_queries;
     DeviceBuf<vfsx_hit> fb_hits;
@@ -448,9 +450,12 @@ struct ScanWorkspace {
 // One pass of the exact scan (k <= kMaxKPerPass hits per query): enqueue scan + select on `s`, no host
 // synchronisation.  Query q's hits go to d_hits[q * out_stride + out_off ..]; with cursor_in the pass ranks only
 // what sorts after each query's cursor, with cursor_out it leaves the next pass's cursors.
+// long_k != 0 (result_limit > kLongResultK; never with ws or the integer-domain metric): the scan writes every row's
+// composite key instead of lists and the long_k hits per query come from the radix select (vfsx_kernels.hip, "long
+// results"); k must be 1 then (it only sizes the unused list LDS).
 void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric, vfsx_hit *d_hits,
                      uint32_t out_stride, uint32_t out_off, const uint64_t *cursor_in, uint64_t *cursor_out,
-                     hipStream_t s, const ScanWorkspace *ws)
+                     hipStream_t s, const ScanWorkspace *ws, uint32_t long_k = 0)
 {
     const bool i8dom = metric == VFSX_EUCLIDEAN_I8DOMAIN;
     const bool profiling = c->profiling && !ws; // event creation allocates: never on the no-allocation path
@@ -510,7 +515,7 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
     }
     // single-query int8 scans of big corpora: 16-wave workgroups around one 64 KiB table (vfsx_kernels.hip)
     const bool wide = c->dtype == VFSX_I8 && !i8dom && nq_per_pass == 1 && k <= 64u && c->i8_wide != 0 &&
-                      n_rowblocks >= 16u * c->n_cus && !cursor_in; // (only scan_kernel knows about cursors)
+                      n_rowblocks >= 16u * c->n_cus && !cursor_in && !long_k; // (only scan_kernel knows about cursors / keys)
     const uint32_t wg_waves = wide ? vfsx::kWideScanWaves : 4u;
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + wg_waves - 1u) / wg_waves,
                                          wide ? c->n_cus * c->i8_wide : c->max_blocks);
@@ -529,7 +534,8 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
     uint32_t q_per_launch = std::min<uint32_t>(nq, stage_cap);
     uint64_t *lists = nullptr;
     if (grid_x) {
-        const uint64_t per_q = (uint64_t)grid_x * k * sizeof(uint64_t);
+        const uint64_t per_q = long_k ? (uint64_t)n_rowblocks * 64u * sizeof(uint64_t) // every row's key
+                                      : (uint64_t)grid_x * k * sizeof(uint64_t);
         const uint64_t lists_bytes = ws ? ws->lists_elems * sizeof(uint64_t) : (256ull << 20);
         if (ws && per_q > lists_bytes)
             fail(VFSX_ERR_INVALID_VECTOR, "vfsx_search_device_noalloc: " + std::to_string(grid_x) + " workgroup lists of k = " +
@@ -537,8 +543,17 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
         q_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(q_per_launch, lists_bytes / per_q));
         q_per_launch = std::min<uint32_t>(q_per_launch, 32768u);
         if (!ws)
-            c->lists.reserve((size_t)q_per_launch * grid_x * k);
+            c->lists.reserve((size_t)q_per_launch * per_q / sizeof(uint64_t));
         lists = ws ? ws->lists : c->lists.p;
+        if (long_k) {
+            const size_t st_words = ((size_t)q_per_launch * vfsx::long_state_bytes() + 3u) / 4u;
+            c->long_state.reserve(st_words);
+            c->long_sel.reserve((size_t)q_per_launch * vfsx::kLongChunkHits);
+            if (c->long_hist.n < (size_t)q_per_launch * 256u) {
+                c->long_hist.reserve((size_t)q_per_launch * 256u);
+                HIP_CHECK(hipMemsetAsync(c->long_hist.p, 0, c->long_hist.n * sizeof(uint32_t), s)); // zero between selects
+            }
+        }
     }
     for (uint32_t q0 = 0; q0 < nq; q0 += q_per_launch) {
         const uint32_t qn = std::min(q_per_launch, nq - q0);
@@ -558,6 +573,7 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
             a.k = k;
             a.n_lists = grid_x;
             a.cursor = cursor_in ? cursor_in + q0 : nullptr;
+            a.write_all = long_k != 0;
             size_t slot = 0;
             if (profiling)
                 prof_begin(c, s, slot);
@@ -569,6 +585,21 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
                 HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
             if (profiling)
                 prof_end(c, s, slot);
+        }
+        if (long_k) {
+            vfsx_hit *out = d_hits + (size_t)q0 * out_stride + out_off;
+            if (!grid_x) { // empty corpus: no hits
+                HIP_CHECK(vfsx::launch_empty_hits(out, qn, long_k, out_stride, s));
+                continue;
+            }
+            HIP_CHECK(hipMemsetAsync(c->long_state.p, 0, (size_t)qn * vfsx::long_state_bytes(), s)); // no cursor yet
+            for (uint32_t off = 0; off < long_k; off += vfsx::kLongChunkHits) {
+                const uint32_t kp = std::min(vfsx::kLongChunkHits, long_k - off);
+                HIP_CHECK(vfsx::launch_long_select(lists, n_rowblocks * 64u, qn, kp, c->long_state.p, c->long_hist.p,
+                                                   c->long_sel.p, c->explicit_ids ? c->d_ids : nullptr, out, c->row_base,
+                                                   c->id_base, out_stride, off, s));
+            }
+            continue;
         }
         SelectArgs sa{};
         sa.lists = lists;
@@ -605,6 +636,10 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
     if (c->prof_used > 4096)
         prof_collect(c);
     constexpr uint32_t P = vfsx::kMaxKPerPass;
+    if (k > vfsx::kLongResultK && !ws && !i8dom) { // long results: one scan, then the radix select (any k)
+        exact_scan_pass(c, d_queries, nq, 1, metric, d_hits, k, 0, nullptr, nullptr, s, nullptr, k);
+        return;
+    }
     if (k <= P) {
         exact_scan_pass(c, d_queries, nq, k, metric, d_hits, k, 0, nullptr, nullptr, s, ws);
         return;
@@ -1097,6 +1132,9 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->q_norm.release();
     c->q_eps.release();
     c->q_scale.release();
+    c->long_state.release();
+    c->long_hist.release();
+    c->long_sel.release();
     c->fb_idx.release();
     c->fb_queries.release();
     c->fb_hits.release();

@@ -79,6 +79,7 @@ __device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v)
 // k <= 64: lane i holds the i-th smallest key; no memory traffic at all.
 struct WaveTopKReg {
     static constexpr bool kInRegisters = true;
+    static constexpr bool kWriteAll = false;
     uint64_t e;
     uint64_t tau;
     uint32_t k;
@@ -127,6 +128,7 @@ struct WaveTopKReg {
 // still several times cheaper than the LDS list below.
 struct WaveTopKReg2 {
     static constexpr bool kInRegisters = true;
+    static constexpr bool kWriteAll = false;
     uint64_t e0, e1;
     uint64_t tau;
     uint32_t k;
@@ -182,6 +184,7 @@ struct WaveTopKReg2 {
 // any k: the list lives in LDS (one per wave), ascending, kSentinel padded.
 struct WaveTopKLds {
     static constexpr bool kInRegisters = false;
+    static constexpr bool kWriteAll = false;
     uint64_t *L;
     uint64_t tau;
     uint32_t k;
@@ -241,6 +244,18 @@ struct WaveTopKLds {
             dst[i * stride] = L[i];
     }
     __device__ __forceinline__ void spill(uint64_t *) const {} // the list already lives in the wave's LDS row
+};
+
+// No list at all: the scan writes every row's composite key to HBM ([query][row], kSentinel for rows that do not
+// exist) and a radix select over them finds the k smallest (result_limit > 128: vfsx_kernels.hip, "long results").
+struct WaveWriteAll {
+    static constexpr bool kInRegisters = true;
+    static constexpr bool kWriteAll = true;
+    uint64_t tau;
+    __device__ __forceinline__ void init(uint32_t, uint64_t *) { tau = kSentinel; }
+    __device__ __forceinline__ void offer(uint64_t) {}
+    __device__ __forceinline__ void store(uint64_t *, size_t = 1) const {}
+    __device__ __forceinline__ void spill(uint64_t *) const {}
 };
 
 // ---- distance accumulation -----------------------------------------------------

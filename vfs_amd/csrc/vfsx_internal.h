@@ -45,6 +45,8 @@ struct ScanArgs {
     uint32_t n_lists; // = gridDim.x (one list per workgroup)
     const uint64_t *cursor; // [nq] or nullptr: rank only composite keys strictly above the query's cursor
                             // (scan_kernel only; the pass mechanism behind result_limit > kMaxKPerPass)
+    bool write_all;         // scan_kernel only: no lists -- `lists` receives every row's composite key,
+                            // [nq][64 n_rowblocks] (kSentinel past n_rows), for the radix select below
 };
 constexpr uint32_t kMaxKPerPass = 1024; // longest list one scan pass keeps per wave (LDS)
 
@@ -71,6 +73,14 @@ constexpr uint32_t kWideScanWaves = 16;
 hipError_t launch_scan_i8_wide(int metric, const ScanArgs &a, uint32_t nq, uint32_t grid_x, bool nt, int unroll,
                                hipStream_t s);
 hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s);
+// result_limit > kLongResultK: scan_kernel with ScanArgs::write_all, then chunks of launch_long_select (vfsx_kernels.hip)
+constexpr uint32_t kLongResultK = 128;  // beyond this the lists give way to the radix select
+constexpr uint32_t kLongChunkHits = 4096; // hits one select / sort chunk emits per query
+size_t long_state_bytes();
+hipError_t launch_empty_hits(vfsx_hit *out, uint32_t nq, uint32_t k, uint32_t out_stride, hipStream_t s);
+hipError_t launch_long_select(const uint64_t *keys, uint32_t n, uint32_t nq, uint32_t kp, void *state, uint32_t *hist,
+                              uint64_t *sel, const uint64_t *ids, vfsx_hit *out, uint64_t row_base, uint64_t id_base,
+                              uint32_t out_stride, uint32_t out_off, hipStream_t s);
 hipError_t launch_query_pad(const float *d_queries_in, uint32_t nq, uint32_t dim, float *d_q_padded,
                             uint32_t q_stride, hipStream_t s);
 hipError_t launch_lut(float scale, float *d_lut, hipStream_t s);

@@ -118,7 +118,12 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                 if (cursor && comp <= cur[n])
                     comp = kSentinel;
             }
-            top[n].offer(comp);
+            if (TopK::kWriteAll) { // `lists` is the key buffer [nq][64 n_rowblocks]: one coalesced 512 B store per wave
+                if (q0 + n < nq)
+                    lists[(size_t)(q0 + n) * n_rowblocks * 64u + row] = comp;
+            } else {
+                top[n].offer(comp);
+            }
         }
     };
 
@@ -193,6 +198,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
         }
     }
 
+    if (TopK::kWriteAll)
+        return;
     // fold the 4 waves' lists into wave 0's, then one list per workgroup and query to HBM
     __syncthreads(); // (TopKLds: lists already live there; Reg: publish them)
 #pragma unroll
@@ -402,6 +409,195 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
         }
         if (cursor_out && lane == 0)
             cursor_out[qi] = mine[k - 1]; // kSentinel when fewer than k rows were left: later passes find nothing
+    }
+}
+
+// ---- long results (result_limit > 128): radix select over every row's composite key ----------------------
+// A wave scanning 256 rows cannot keep a 1000-entry list profitably (every row is an insert, and the select
+// then merges ~1000 lists of 1000): C2 at k = 1000 took 10 ms per query that way.  Instead scan_kernel<WaveWriteAll>
+// writes all composite keys (8 B per row: 0.3 % of the bytes the scan reads at d = 768) and the k smallest are
+// found by an 8-pass radix select, most significant byte first.  Keys are unique (they embed the row), so after the
+// last pass `prefix` IS the k-th smallest key above the query's cursor and exactly k keys lie in (cursor, prefix]:
+// they are compacted, sorted by one workgroup (bitonic, <= kLongChunk entries) and emitted.  Longer results repeat
+// select / compact / sort from the new cursor -- the scan runs ONCE however long the result is.
+struct LongState { // per query
+    uint64_t lo;     // cursor: only keys > lo count (has_lo != 0)
+    uint64_t prefix; // the bytes of the k-th key decided so far (most significant first)
+    uint32_t has_lo;
+    uint32_t k_rem;  // rank of the wanted key among the keys that match `prefix`
+    uint32_t count;  // compaction cursor
+    uint32_t pad;
+};
+
+__device__ __forceinline__ bool long_in_play(uint64_t key, const LongState &st, uint32_t byte)
+{
+    if (st.has_lo && key <= st.lo)
+        return false;
+    return byte == 7u || (key >> (8u * (byte + 1u))) == (st.prefix >> (8u * (byte + 1u)));
+}
+
+__global__ void long_set_rank_kernel(LongState *__restrict__ state, uint32_t nq, uint32_t kp)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) {
+        state[q].k_rem = kp;
+        state[q].prefix = 0;
+        state[q].count = 0;
+    }
+}
+
+// grid (blocks, queries), 256 threads, kLongKeysPerBlock keys per block: histogram of byte `byte` over the keys in play
+constexpr uint32_t kLongKeysPerBlock = 16384;
+__global__ __launch_bounds__(256) void long_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n,
+                                                        const LongState *__restrict__ state, uint32_t *__restrict__ hist,
+                                                        uint32_t byte)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const LongState st = state[blockIdx.y];
+    const uint64_t *kq = keys + (size_t)blockIdx.y * n;
+    const uint32_t i0 = blockIdx.x * kLongKeysPerBlock;
+    const uint32_t i1 = min(n, i0 + kLongKeysPerBlock);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256u) {
+        const uint64_t key = kq[i];
+        if (long_in_play(key, st, byte))
+            atomicAdd(&h[(uint32_t)(key >> (8u * byte)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x])
+        atomicAdd(&hist[blockIdx.y * 256u + threadIdx.x], h[threadIdx.x]);
+}
+
+// one wave per query: the bin in which the k_rem-th key in play falls becomes the next byte of `prefix`
+__global__ __launch_bounds__(64) void long_pick_kernel(LongState *__restrict__ state, uint32_t *__restrict__ hist,
+                                                       uint32_t byte)
+{
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    uint32_t *hq = hist + q * 256u;
+    uint32_t c[4], own = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = hq[lane * 4u + j];
+        hq[lane * 4u + j] = 0; // ready for the next pass
+        own += c[j];
+    }
+    uint32_t incl = own; // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o)
+            incl += v;
+    }
+    LongState st = state[q];
+    const uint32_t excl = incl - own;
+    // the first bin whose inclusive count reaches k_rem (none: fewer keys than asked for -> the last bin, and the
+    // select ends on kSentinel, which the compaction drops)
+    uint32_t bin = 256u, below = 0;
+    uint32_t run = excl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (bin == 256u && run + c[j] >= st.k_rem) {
+            bin = lane * 4u + (uint32_t)j;
+            below = run;
+        }
+        run += c[j];
+    }
+    const uint64_t has = __ballot(bin != 256u);
+    uint32_t pick_bin = 255u, pick_below = 0;
+    if (has) {
+        const int l = __builtin_ctzll(has);
+        pick_bin = (uint32_t)__shfl((int)bin, l, 64);
+        pick_below = (uint32_t)__shfl((int)below, l, 64);
+    } else {
+        pick_below = (uint32_t)__shfl((int)(incl), 63, 64) - (uint32_t)__shfl((int)c[3], 63, 64); // keys below bin 255
+    }
+    if (lane == 0) {
+        st.prefix |= (uint64_t)pick_bin << (8u * byte);
+        st.k_rem = st.k_rem > pick_below ? st.k_rem - pick_below : 1u;
+        state[q] = st;
+    }
+}
+
+// grid (blocks, queries): the keys in (cursor, prefix] (kSentinel excluded) -> sel[q][0 .. count), unordered
+__global__ __launch_bounds__(256) void long_compact_kernel(const uint64_t *__restrict__ keys, uint32_t n,
+                                                           LongState *__restrict__ state, uint64_t *__restrict__ sel,
+                                                           uint32_t sel_stride)
+{
+    const LongState st = state[blockIdx.y];
+    const uint64_t *kq = keys + (size_t)blockIdx.y * n;
+    const uint32_t i0 = blockIdx.x * kLongKeysPerBlock;
+    const uint32_t i1 = min(n, i0 + kLongKeysPerBlock);
+    for (uint32_t base = i0; base < i1; base += 256u) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t key = i < i1 ? kq[i] : kSentinel;
+        const bool take = key != kSentinel && key <= st.prefix && !(st.has_lo && key <= st.lo);
+        const uint64_t m = __ballot(take);
+        if (m) { // one atomic per wave
+            uint32_t pos0 = 0;
+            if (lane_id() == 0)
+                pos0 = atomicAdd(&state[blockIdx.y].count, (uint32_t)__popcll(m));
+            pos0 = (uint32_t)__shfl((int)pos0, 0, 64);
+            const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+            if (take && pos < sel_stride)
+                sel[(size_t)blockIdx.y * sel_stride + pos] = key;
+        }
+    }
+}
+
+// one 1024-thread workgroup per query: sort the compacted keys (bitonic, kLongChunk slots in LDS), emit the hits of
+// this chunk at out[q * out_stride + out_off ..], move the cursor to the chunk's last key
+constexpr uint32_t kLongChunk = 4096;
+__global__ __launch_bounds__(1024) void long_sort_emit_kernel(const uint64_t *__restrict__ sel, LongState *__restrict__ state,
+                                                              const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out,
+                                                              uint64_t row_base, uint64_t id_base, uint32_t kp,
+                                                              uint32_t out_stride, uint32_t out_off)
+{
+    __shared__ uint64_t s_key[kLongChunk];
+    const uint32_t q = blockIdx.x;
+    const uint32_t count = min(state[q].count, kp);
+    for (uint32_t i = threadIdx.x; i < kLongChunk; i += 1024u)
+        s_key[i] = i < count ? sel[(size_t)q * kLongChunk + i] : kSentinel;
+    __syncthreads();
+    for (uint32_t size = 2; size <= kLongChunk; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < kLongChunk / 2u; t += 1024u) {
+                const uint32_t i = 2u * t - (t & (stride - 1u)); // the lower index of pair t at this stride
+                const uint32_t j = i + stride;
+                const bool up = (i & size) == 0u;
+                const uint64_t a = s_key[i], b = s_key[j];
+                if ((a > b) == up) {
+                    s_key[i] = b;
+                    s_key[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t j = threadIdx.x; j < kp; j += 1024u) {
+        const uint64_t comp = s_key[j];
+        vfsx_hit h;
+        if (comp == kSentinel) {
+            h.dist = __uint_as_float(0x7fc00000u);
+            h.flags = 0;
+            h.row = ~0ull;
+            h.id = ~0ull;
+        } else {
+            const uint32_t r = (uint32_t)comp;
+            h.dist = key_dist((uint32_t)(comp >> 32));
+            h.flags = 1;
+            h.row = row_base + r;
+            h.id = ids ? ids[r] : id_base + r;
+        }
+        out[(size_t)q * out_stride + out_off + j] = h;
+    }
+    if (threadIdx.x == 0) { // next chunk: everything after this chunk's last key (kSentinel: nothing is left)
+        LongState st = state[q];
+        st.lo = count == kp ? s_key[kp - 1u] : kSentinel;
+        st.has_lo = 1;
+        st.prefix = 0;
+        st.count = 0;
+        state[q] = st;
     }
 }
 
@@ -723,7 +919,11 @@ static hipError_t launch_scan_v(const ScanArgs &a, uint32_t nq, uint32_t grid_x,
 {
     dim3 grid(grid_x, (nq + NQ - 1) / NQ), block(kBlock);
     const size_t lds = scan_lds_bytes(a.k, NQ, a.q_stride);
-    if (a.k <= kMaxRegisterK) {
+    if (a.write_all) { // long results: every row's key to HBM, no lists (a.k = 1 sizes the unused list LDS)
+        hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveWriteAll, UNROLL, NT, NQ, false>), grid, block, lds, s,
+                           a.corpus, a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
+                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
+    } else if (a.k <= kMaxRegisterK) {
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
                            a.q_stride, a.k, a.n_lists, nq, a.cursor);
@@ -841,6 +1041,48 @@ hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)
         hipLaunchKernelGGL((select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
                            a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k, a.cursor_out);
     }
+    return hipGetLastError();
+}
+
+// long results: one chunk (kp <= kLongChunk hits per query from the current cursors) of the radix select over `keys`
+// ([nq][n] composite keys written by scan_kernel<WaveWriteAll>); state / hist / sel are the caller's workspaces
+// (state[q].k_rem is set here; hist must be zero on entry and is zero again on return)
+hipError_t launch_long_select(const uint64_t *keys, uint32_t n, uint32_t nq, uint32_t kp, void *state, uint32_t *hist,
+                              uint64_t *sel, const uint64_t *ids, vfsx_hit *out, uint64_t row_base, uint64_t id_base,
+                              uint32_t out_stride, uint32_t out_off, hipStream_t s)
+{
+    LongState *st = (LongState *)state;
+    const dim3 grid((n + kLongKeysPerBlock - 1u) / kLongKeysPerBlock, nq);
+    hipLaunchKernelGGL(long_set_rank_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, s, st, nq, kp);
+    for (int byte = 7; byte >= 0; --byte) {
+        hipLaunchKernelGGL(long_hist_kernel, grid, dim3(256), 0, s, keys, n, st, hist, (uint32_t)byte);
+        hipLaunchKernelGGL(long_pick_kernel, dim3(nq), dim3(64), 0, s, st, hist, (uint32_t)byte);
+    }
+    hipLaunchKernelGGL(long_compact_kernel, grid, dim3(256), 0, s, keys, n, st, sel, kLongChunk);
+    hipLaunchKernelGGL(long_sort_emit_kernel, dim3(nq), dim3(1024), 0, s, sel, st, ids, out, row_base, id_base, kp,
+                       out_stride, out_off);
+    return hipGetLastError();
+}
+
+size_t long_state_bytes() { return sizeof(LongState); }
+
+__global__ void empty_hits_kernel(vfsx_hit *__restrict__ out, uint32_t nq, uint32_t k, uint32_t out_stride)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)nq * k)
+        return;
+    vfsx_hit h;
+    h.dist = __uint_as_float(0x7fc00000u);
+    h.flags = 0;
+    h.row = ~0ull;
+    h.id = ~0ull;
+    out[(t / k) * out_stride + t % k] = h;
+}
+
+hipError_t launch_empty_hits(vfsx_hit *out, uint32_t nq, uint32_t k, uint32_t out_stride, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)nq * k;
+    hipLaunchKernelGGL(empty_hits_kernel, dim3((uint32_t)((total + 255u) / 256u)), dim3(256), 0, s, out, nq, k, out_stride);
     return hipGetLastError();
 }
 
