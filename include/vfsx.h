@@ -362,9 +362,10 @@ int vfsx_corpus_mfma_mirror(vfsx_corpus *c, int *kind, float *residual);
 int vfsx_corpus_set_profiling(vfsx_corpus *c, int enabled);
 int vfsx_corpus_scan_time_ms(vfsx_corpus *c, double *total_ms, uint64_t *launches, int reset);
 
-/* Largest result_limit.  Up to 1024 hits come from one pass over the corpus; a longer result takes
- * ceil(k / 1024) passes (each pass ranks what sorts after the previous pass's last hit).  The reference's
- * limit is unbounded (rank.rs:129,172-173); this bound only keeps result buffers addressable. */
+/* Largest result_limit.  Any length comes from ONE pass over the corpus: up to 128 hits from per-wavefront lists,
+ * longer results from a radix select over every row's (distance, row) key.  The reference's limit is unbounded
+ * (rank.rs:129,172-173); this bound only keeps result buffers addressable.  vfsx_search_device_noalloc and
+ * VFSX_EUCLIDEAN_I8DOMAIN serve k <= 1024. */
 #define VFSX_MAX_K (1u << 20)
 
 #ifdef __cplusplus

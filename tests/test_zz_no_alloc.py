@@ -76,7 +76,7 @@ def test_noalloc_large_k_many_queries_and_limits():
         huge.search_device_noalloc(qh.data_ptr(), 1, 1, 0, out.data_ptr(), 0)
     assert e.value.code == vfs_amd._lib.ERR_INVALID_VECTOR and "static workspace" in str(e.value)
     huge.close()
-    with pytest.raises(vfs_amd.VfsxError) as e:  # results beyond one pass (k > 1024) need a cursor buffer
+    with pytest.raises(vfs_amd.VfsxError) as e:  # longer results need the key buffer of the radix select
         c.search_device_noalloc(q.data_ptr(), 1, 2000, 0, out.data_ptr(), 0)
     assert "limited to 1024" in str(e.value)
     c.close()

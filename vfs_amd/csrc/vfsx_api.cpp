@@ -148,7 +148,7 @@ struct vfsx_corpus {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
 
     // search workspace
-    DeviceBuf<uint64_t> lists, cursor;
+    DeviceBuf<uint64_t> lists;
     DeviceBuf<float> q_in, q_pad;
     DeviceBuf<vfsx_hit> hits;
     DeviceBuf<uint64_t> row_idx;
@@ -448,16 +448,15 @@ struct ScanWorkspace {
 };
 
 // One pass of the exact scan (k <= kMaxKPerPass hits per query): enqueue scan + select on `s`, no host
-// synchronisation.  Query q's hits go to d_hits[q * out_stride + out_off ..]; with cursor_in the pass ranks only
-// what sorts after each query's cursor, with cursor_out it leaves the next pass's cursors.
+// synchronisation.  Query q's hits go to d_hits[q * (long_k ? long_k : k) ..].
 // long_k != 0 (result_limit > kLongResultK; never with ws or the integer-domain metric): the scan writes every row's
 // composite key instead of lists and the long_k hits per query come from the radix select (vfsx_kernels.hip, "long
 // results"); k must be 1 then (it only sizes the unused list LDS).
 void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric, vfsx_hit *d_hits,
-                     uint32_t out_stride, uint32_t out_off, const uint64_t *cursor_in, uint64_t *cursor_out,
                      hipStream_t s, const ScanWorkspace *ws, uint32_t long_k = 0)
 {
     const bool i8dom = metric == VFSX_EUCLIDEAN_I8DOMAIN;
+    const uint32_t out_stride = long_k ? long_k : k;
     const bool profiling = c->profiling && !ws; // event creation allocates: never on the no-allocation path
 
     // queries the kernels cannot read in place are staged: quantized and packed for the integer-domain
@@ -515,7 +514,7 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
     }
     // single-query int8 scans of big corpora: 16-wave workgroups around one 64 KiB table (vfsx_kernels.hip)
     const bool wide = c->dtype == VFSX_I8 && !i8dom && nq_per_pass == 1 && k <= 64u && c->i8_wide != 0 &&
-                      n_rowblocks >= 16u * c->n_cus && !cursor_in && !long_k; // (only scan_kernel knows about cursors / keys)
+                      n_rowblocks >= 16u * c->n_cus && !long_k; // (only scan_kernel writes keys)
     const uint32_t wg_waves = wide ? vfsx::kWideScanWaves : 4u;
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + wg_waves - 1u) / wg_waves,
                                          wide ? c->n_cus * c->i8_wide : c->max_blocks);
@@ -572,7 +571,6 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
             a.q_stride = q_stride;
             a.k = k;
             a.n_lists = grid_x;
-            a.cursor = cursor_in ? cursor_in + q0 : nullptr;
             a.write_all = long_k != 0;
             size_t slot = 0;
             if (profiling)
@@ -587,7 +585,7 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
                 prof_end(c, s, slot);
         }
         if (long_k) {
-            vfsx_hit *out = d_hits + (size_t)q0 * out_stride + out_off;
+            vfsx_hit *out = d_hits + (size_t)q0 * out_stride;
             if (!grid_x) { // empty corpus: no hits
                 HIP_CHECK(vfsx::launch_empty_hits(out, qn, long_k, out_stride, s));
                 continue;
@@ -604,13 +602,12 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
         SelectArgs sa{};
         sa.lists = lists;
         sa.ids = c->explicit_ids ? c->d_ids : nullptr;
-        sa.out = d_hits + (size_t)q0 * out_stride + out_off;
+        sa.out = d_hits + (size_t)q0 * out_stride;
         sa.row_base = c->row_base;
         sa.id_base = c->id_base;
         sa.n_lists = grid_x;
         sa.k = k;
         sa.out_stride = out_stride;
-        sa.cursor_out = cursor_out ? cursor_out + q0 : nullptr;
         HIP_CHECK(vfsx::launch_select(sa, qn, s));
     }
 }
@@ -637,27 +634,16 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
         prof_collect(c);
     constexpr uint32_t P = vfsx::kMaxKPerPass;
     if (k > vfsx::kLongResultK && !ws && !i8dom) { // long results: one scan, then the radix select (any k)
-        exact_scan_pass(c, d_queries, nq, 1, metric, d_hits, k, 0, nullptr, nullptr, s, nullptr, k);
+        exact_scan_pass(c, d_queries, nq, 1, metric, d_hits, s, nullptr, k);
         return;
     }
-    if (k <= P) {
-        exact_scan_pass(c, d_queries, nq, k, metric, d_hits, k, 0, nullptr, nullptr, s, ws);
-        return;
-    }
-    // result_limit beyond one pass (the reference's limit is unbounded, rank.rs:129,172-173): ceil(k / 1024)
-    // passes over the corpus, pass p ranking what sorts strictly after the (unique) composite key its
-    // predecessor ended on -- the concatenation is the ranking a single longer list would give
-    if (ws)
+    // the list path: per-wave lists of at most P entries
+    if (k > P && ws)
         fail(VFSX_ERR_INVALID_VECTOR, "vfsx_search_device_noalloc: k is limited to " + std::to_string(P) +
-                                          " (the passes of a longer result need a cursor buffer)");
-    if (i8dom)
+                                          " (a longer result needs the key buffer of the radix select)");
+    if (k > P)
         fail(VFSX_ERR_INVALID_VECTOR, "the integer-domain extension supports k <= " + std::to_string(P));
-    c->cursor.reserve(nq);
-    for (uint32_t off = 0; off < k; off += P) {
-        const uint32_t kp = std::min(P, k - off);
-        exact_scan_pass(c, d_queries, nq, kp, metric, d_hits, k, off, off ? c->cursor.p : nullptr,
-                        off + kp < k ? c->cursor.p : nullptr, s, nullptr);
-    }
+    exact_scan_pass(c, d_queries, nq, k, metric, d_hits, s, ws);
 }
 
 void free_mirror(vfsx_corpus *c)
@@ -1142,7 +1128,6 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->cand.release();
     c->sel.release();
     c->lists.release();
-    c->cursor.release();
     c->q_in.release();
     c->q_pad.release();
     c->hits.release();

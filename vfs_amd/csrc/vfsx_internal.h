@@ -43,12 +43,10 @@ struct ScanArgs {
     uint32_t q_stride;
     uint32_t k;
     uint32_t n_lists; // = gridDim.x (one list per workgroup)
-    const uint64_t *cursor; // [nq] or nullptr: rank only composite keys strictly above the query's cursor
-                            // (scan_kernel only; the pass mechanism behind result_limit > kMaxKPerPass)
     bool write_all;         // scan_kernel only: no lists -- `lists` receives every row's composite key,
                             // [nq][64 n_rowblocks] (kSentinel past n_rows), for the radix select below
 };
-constexpr uint32_t kMaxKPerPass = 1024; // longest list one scan pass keeps per wave (LDS)
+constexpr uint32_t kMaxKPerPass = 1024; // longest list a wave keeps (LDS): the limit of the list path (no-alloc entry, integer-domain metric)
 
 struct SelectArgs {
     const uint64_t *lists; // [nq][k][n_lists]
@@ -59,7 +57,6 @@ struct SelectArgs {
     uint32_t n_lists;
     uint32_t k;
     uint32_t out_stride;  // hits per query in `out` (0 = k)
-    uint64_t *cursor_out; // [nq] or nullptr: the composite key of each query's k-th entry
 };
 
 // launchers (vfsx_kernels.hip). All enqueue on `s` and return the launch status.

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
     const float *__restrict__ queries, const float *__restrict__ lut, uint64_t *__restrict__ lists,
     uint32_t n_rows, uint32_t d_chunks, uint32_t n_rowblocks, uint32_t q_stride, uint32_t k,
-    uint32_t n_lists, uint32_t nq, const uint64_t *__restrict__ cursor)
+    uint32_t n_lists, uint32_t nq)
 {
     extern __shared__ __align__(16) uint64_t dyn_lds[];
     __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 * 32 : 1];
@@ -90,12 +90,6 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
         qn[n] = 0.0f;
-    // result_limit beyond one pass (k > 1024): this pass ranks only what sorts strictly after the query's
-    // cursor, the last composite key of the previous pass (keys are unique, so the passes tile the ranking)
-    uint64_t cur[NQ];
-#pragma unroll
-    for (int n = 0; n < NQ; ++n)
-        cur[n] = cursor ? cursor[min(q0 + (uint32_t)n, nq - 1u)] : 0ull;
 
     // distance of row (64 blk + lane) from its finished accumulators, offered to the wave's lists
     auto finish_rowblock = [&](uint32_t blk, Acc(&acc)[NQ]) {
@@ -115,8 +109,6 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                     dist = f_sub(1.0f, f_div(acc[n].a, den));
                 }
                 comp = ((uint64_t)dist_key(dist) << 32) | row;
-                if (cursor && comp <= cur[n])
-                    comp = kSentinel;
             }
             if (TopK::kWriteAll) { // `lists` is the key buffer [nq][64 n_rowblocks]: one coalesced 512 B store per wave
                 if (q0 + n < nq)
@@ -339,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
                                                             const uint64_t *__restrict__ ids,
                                                             vfsx_hit *__restrict__ out, uint64_t row_base,
                                                             uint64_t id_base, uint32_t n_lists, uint32_t k,
-                                                            uint32_t out_stride, uint64_t *__restrict__ cursor_out)
+                                                            uint32_t out_stride)
 {
     constexpr uint32_t BLOCK = 64u * WAVES;
     extern __shared__ __align__(16) uint64_t dyn_lds[];
@@ -407,8 +399,6 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
             }
             out[(size_t)qi * out_stride + j] = h;
         }
-        if (cursor_out && lane == 0)
-            cursor_out[qi] = mine[k - 1]; // kSentinel when fewer than k rows were left: later passes find nothing
     }
 }
 
@@ -922,20 +912,20 @@ static hipError_t launch_scan_v(const ScanArgs &a, uint32_t nq, uint32_t grid_x,
     if (a.write_all) { // long results: every row's key to HBM, no lists (a.k = 1 sizes the unused list LDS)
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveWriteAll, UNROLL, NT, NQ, false>), grid, block, lds, s,
                            a.corpus, a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
+                           a.q_stride, a.k, a.n_lists, nq);
     } else if (a.k <= kMaxRegisterK) {
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
+                           a.q_stride, a.k, a.n_lists, nq);
     } else if (a.k <= kMaxRegister2K && NQ == 1 && !PIPE) { // single-query scans with 64 < k <= 128 (the reference's own
         // benchmark asks for 100): two registers per lane instead of the LDS list (C2, k = 100: 0.54 -> 0.47 ms)
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKReg2, UNROLL, NT, NQ, false>), grid, block, lds, s,
                            a.corpus, a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
+                           a.q_stride, a.k, a.n_lists, nq);
     } else {
         hipLaunchKernelGGL((scan_kernel<DTYPE, METRIC, WaveTopKLds, UNROLL, NT, NQ, PIPE>), grid, block, lds, s, a.corpus,
                            a.row_norms, a.queries, a.lut, a.lists, a.n_rows, a.d_chunks, a.n_rowblocks,
-                           a.q_stride, a.k, a.n_lists, nq, a.cursor);
+                           a.q_stride, a.k, a.n_lists, nq);
     }
     return hipGetLastError();
 }
@@ -1029,17 +1019,17 @@ hipError_t launch_select(const SelectArgs &a, uint32_t nq, hipStream_t s)
         constexpr int W = 16;
         const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
         hipLaunchKernelGGL((select_kernel<WaveTopKReg, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
-                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k, a.cursor_out);
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k);
     } else if (a.k <= kMaxRegister2K) {
         constexpr int W = 16;
         const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
         hipLaunchKernelGGL((select_kernel<WaveTopKReg2, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
-                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k, a.cursor_out);
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k);
     } else {
         constexpr int W = 4;
         const size_t lds = (size_t)W * list_stride * sizeof(uint64_t);
         hipLaunchKernelGGL((select_kernel<WaveTopKLds, W>), dim3(nq), dim3(64 * W), lds, s, a.lists, a.ids,
-                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k, a.cursor_out);
+                           a.out, a.row_base, a.id_base, a.n_lists, a.k, a.out_stride ? a.out_stride : a.k);
     }
     return hipGetLastError();
 }
