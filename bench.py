@@ -328,7 +328,8 @@ def main(argv=None) -> int:
         scan_kernel_name = "scan_i8w_kernel"
     traffic, traffic_source = pmc_traffic(workload, rows)
     out = {
-        "metric": f"exact top-{k} QPS (single-query scan; queries/s against the whole row-sharded corpus)",
+        "metric": (f"exact top-{k} QPS (query batches on the matrix cores + exact re-score; queries/s)" if mfma else
+                   f"exact top-{k} QPS (single-query scan; queries/s against the whole row-sharded corpus)"),
         "value": round(qps_global, 3),
         "unit": "queries/s",
         "n_gpus": world,
