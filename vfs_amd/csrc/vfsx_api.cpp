@@ -159,7 +159,7 @@ struct vfsx_corpus {
     int nt_override = 2;     // 2 = auto
     int pipe_override = 2;   // 2 = auto
     bool balanced_grid = true; // VFSX_BALANCED_GRID=0: always the full grid (A/B measurements)
-    uint32_t i8_wide = 1;      // VFSX_I8_WIDE: 16-wave int8 scan workgroups per CU (0 = off, default 1)
+    uint32_t i8_wide = 3;      // VFSX_I8_WIDE: 16-wave int8 scan workgroups per CU (0 = off, 1, 2; 3 = by corpus size)
     uint32_t n_cus = 0;
 
     // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
@@ -515,9 +515,13 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
     // single-query int8 scans of big corpora: 16-wave workgroups around one 64 KiB table (vfsx_kernels.hip)
     const bool wide = c->dtype == VFSX_I8 && !i8dom && nq_per_pass == 1 && k <= 64u && c->i8_wide != 0 &&
                       n_rowblocks >= 16u * c->n_cus && !long_k; // (only scan_kernel writes keys)
+    // ... one such workgroup per CU, or two (with 8 instead of 4 loads in flight per lane) when every wave still
+    // gets >= 16 row-blocks: C3 212 -> 209.5 us (alone, neither the second workgroup nor the deeper unroll gains)
+    const uint32_t wide_wgs = c->i8_wide != 3u ? c->i8_wide : (n_rowblocks >= 512u * c->n_cus ? 2u : 1u);
+    const int wide_unroll = c->unroll_override ? c->unroll_override : (wide_wgs == 2u ? 8 : 4);
     const uint32_t wg_waves = wide ? vfsx::kWideScanWaves : 4u;
     uint32_t grid_x = std::min<uint32_t>((n_rowblocks + wg_waves - 1u) / wg_waves,
-                                         wide ? c->n_cus * c->i8_wide : c->max_blocks);
+                                         wide ? c->n_cus * wide_wgs : c->max_blocks);
     if (grid_x && !wide) {
         // Even shares when a wave only gets a few row-blocks: with r = ceil(row-blocks / waves), the
         // smallest grid that still covers the corpus gives (almost) every wave exactly r of them, so the
@@ -578,7 +582,7 @@ void exact_scan_pass(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32
             if (i8dom)
                 HIP_CHECK(vfsx::launch_scan_i8dom(a, qn, grid_x, nt != 0, c->scale, s));
             else if (wide)
-                HIP_CHECK(vfsx::launch_scan_i8_wide(metric, a, qn, grid_x, nt != 0, c->unroll_override, s));
+                HIP_CHECK(vfsx::launch_scan_i8_wide(metric, a, qn, grid_x, nt != 0, wide_unroll, s));
             else
                 HIP_CHECK(vfsx::launch_scan(c->dtype, metric, a, qn, grid_x, scan_variant, nq_per_pass, s));
             if (profiling)
@@ -1069,7 +1073,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->pipe_override = (int)env_u64("VFSX_SCAN_PIPE", 2);
         c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
         c->n_cus = (uint32_t)prop.multiProcessorCount;
-        c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 1), 2);
+        c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 3), 3);
         c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 4); // measured crossover (profiles/r02/batch_crossover.txt)
         c->mfma_kp_override = (uint32_t)env_u64("VFSX_MFMA_KP", 0);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
