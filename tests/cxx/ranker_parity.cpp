@@ -97,6 +97,53 @@ int main()
                 compare("literal loop", ranker.search(q, batch, std::nullopt, store), oi, od, cnt);
             }
         }
+        // long results (result_limit > 128: radix select) and the matrix-core batch path under every operand an f32
+        // store can have, through the C++ host mirror
+        {
+            const uint32_t d = 48;
+            const uint64_t n = 20000;
+            std::vector<float> rows(n * d), queries(6 * d);
+            vfso_fill_synthetic_f32(21, 0, n, d, rows.data());
+            vfso_fill_synthetic_f32(22, 0, 6, d, queries.data());
+            vfsx::Corpus store(d);
+            store.register_vectors(rows.data(), n);
+            const std::vector<float> q0(queries.begin(), queries.begin() + d);
+            for (size_t limit : {129u, 1000u, 5000u}) {
+                std::vector<uint64_t> oi(limit);
+                std::vector<float> od(limit);
+                vfsx::Ranker ranker(vfsx::SearchType::Exact, DistanceMethod::Euclidean, limit);
+                const uint64_t cnt = vfso_topk_scan(rows.data(), nullptr, 127.0f, nullptr, n, d, q0.data(), 0, limit,
+                                                    oi.data(), od.data(), nullptr);
+                compare("long result", ranker.search(q0, 64, limit, store), oi.data(), od.data(), cnt);
+            }
+            for (int mirror : {1, 2, 3}) { // auto, bf16, int8
+                store.enable_mfma(true, mirror);
+                const auto kind = store.mfma_mirror();
+                if (kind.first != (mirror == 2 ? 1 : 2)) {
+                    std::printf("FAIL mfma_mirror: asked %d, got kind %d\n", mirror, kind.first);
+                    ++failures;
+                }
+                std::vector<uint64_t> ids(6 * 10);
+                std::vector<float> dist(6 * 10);
+                std::vector<uint32_t> count(6);
+                if (vfsx_search(store.handle(), queries.data(), 6, 10, VFSX_COSINE, ids.data(), dist.data(), count.data()) != VFSX_OK) {
+                    std::printf("FAIL batch search: %s\n", vfsx_last_error());
+                    ++failures;
+                    continue;
+                }
+                for (int qi = 0; qi < 6; ++qi) {
+                    uint64_t oi[10];
+                    float od[10];
+                    const uint64_t cnt = vfso_topk_scan(rows.data(), nullptr, 127.0f, nullptr, n, d, queries.data() + qi * d,
+                                                        1, 10, oi, od, nullptr);
+                    std::vector<std::pair<uint64_t, float>> got;
+                    for (uint32_t j = 0; j < count[qi]; ++j)
+                        got.emplace_back(ids[qi * 10 + j], dist[qi * 10 + j]);
+                    compare("mfma batch", got, oi, od, cnt);
+                }
+            }
+            store.enable_mfma(false);
+        }
         std::printf("%s %d cases, %d failures\n", failures ? "FAIL" : "ok", cases, failures);
         return failures ? 1 : 0;
     } catch (const vfsx::Error &e) {
