@@ -34,3 +34,13 @@ def test_cxx_sharded_search_end_to_end():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert r.stdout.strip().splitlines()[-1].startswith("ok ")
+
+
+def test_wave_topk_primitives():
+    """tests/cxx/wave_topk_check.hip: the lane exchanges, the 64-key bitonic sort and the register lists' bulk paths
+    (offer_dense / merge_list) of vfsx_device.h against a host model and against one-at-a-time inserts."""
+    exe = os.path.join(ROOT, "tests", "cxx", "wave_topk_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.strip().splitlines()[-1].startswith("ok ")

@@ -69,6 +69,97 @@ __device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v)
     return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// ---- wave-wide bitonic network on composite keys ---------------------------------
+// One insert into a register list costs a ballot -> popcount -> shift -> readlane chain (~150 cycles of dependent
+// VALU/SALU hops).  That is the right tool while a row-block beats the k-th best once in a while; it is the wrong one
+// when 64 fresh keys meet an empty list (a wave's first row-block; the select's first column: ~k ln(64 e / k) inserts)
+// or when two sorted lists are merged (workgroup folds, select).  Those go through a compare-exchange network instead:
+// 21 stages sort 64 keys across the wave, 6 stages merge two sorted 64-lists, 9 instructions per stage.
+
+// value of lane (l ^ J): DPP inside a row of 16, the gfx950 permlane swaps across rows
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane32(uint32_t v)
+{
+    const int x = (int)v;
+    if constexpr (J == 1) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        // banks 0 and 2 of a row (lanes 0-3, 8-11) read lane + 4 (row_shl:4), banks 1 and 3 lane - 4 (row_shr:4)
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);
+    } else if constexpr (J == 8) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false); // row_ror:8
+    } else if constexpr (J == 16) {
+        // v_permlane16_swap: odd rows of the first operand <-> even rows of the second.  With both = v the first
+        // becomes (r0, r0, r2, r2), the second (r1, r1, r3, r3): a lane of an even row wants the second
+        const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane_id() & 16u) ? p[0] : p[1];
+    } else {
+        static_assert(J == 32, "xor distance");
+        // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+        const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane_id() & 32u) ? p[0] : p[1];
+    }
+}
+
+// bit l set: lane l keeps the SMALLER key of (own, lane l ^ j) in the stage (size, j) of a bitonic sort whose
+// blocks of `size` lanes alternate direction (size = 64: one block), ascending overall unless `desc`
+constexpr uint64_t bitonic_keep_min(int size, int j, bool desc)
+{
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const bool asc = ((l & size) == 0) != desc;
+        const bool low = (l & j) == 0;
+        if (low == asc)
+            m |= 1ull << l;
+    }
+    return m;
+}
+
+template <int J, uint64_t KEEP_MIN>
+__device__ __forceinline__ uint64_t bitonic_cex(uint64_t v)
+{
+    const uint64_t o = ((uint64_t)xor_lane32<J>((uint32_t)(v >> 32)) << 32) | xor_lane32<J>((uint32_t)v);
+    const uint64_t lt = __builtin_amdgcn_ballot_w64(v < o);
+    return __builtin_amdgcn_inverse_ballot_w64(~(lt ^ KEEP_MIN)) ? v : o; // (own < other) == keep_min ? own : other
+}
+
+// the j = SIZE/2 ... 1 stages of block size SIZE: sorts a sequence that is bitonic within each block
+template <int SIZE, bool DESC>
+__device__ __forceinline__ uint64_t bitonic_merge(uint64_t v)
+{
+    if constexpr (SIZE >= 64)
+        v = bitonic_cex<32, bitonic_keep_min(SIZE, 32, DESC)>(v);
+    if constexpr (SIZE >= 32)
+        v = bitonic_cex<16, bitonic_keep_min(SIZE, 16, DESC)>(v);
+    if constexpr (SIZE >= 16)
+        v = bitonic_cex<8, bitonic_keep_min(SIZE, 8, DESC)>(v);
+    if constexpr (SIZE >= 8)
+        v = bitonic_cex<4, bitonic_keep_min(SIZE, 4, DESC)>(v);
+    if constexpr (SIZE >= 4)
+        v = bitonic_cex<2, bitonic_keep_min(SIZE, 2, DESC)>(v);
+    return bitonic_cex<1, bitonic_keep_min(SIZE, 1, DESC)>(v);
+}
+
+// lane l <- the (l+1)-th largest of the wave's 64 keys
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v)
+{
+    v = bitonic_merge<2, true>(v);
+    v = bitonic_merge<4, true>(v);
+    v = bitonic_merge<8, true>(v);
+    v = bitonic_merge<16, true>(v);
+    v = bitonic_merge<32, true>(v);
+    return bitonic_merge<64, true>(v);
+}
+
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+// more fresh keys than this below the k-th best: sort them and merge instead of inserting one by one
+constexpr uint32_t kBulkOfferMin = 6;
+
 // ---- per-wave sorted top-k of composite keys ----------------------------------
 // Composite keys are unique (they embed the row), so insertion order is irrelevant
 // and "strictly smaller than the current k-th" is the exact acceptance test: a row
@@ -97,9 +188,8 @@ struct WaveTopKReg {
         e = lane < p ? e : (lane == p ? c : up);
         tau = readlane64(e, k - 1);
     }
-    __device__ __forceinline__ void offer(uint64_t comp)
+    __device__ __forceinline__ void offer_some(uint64_t m, uint64_t comp)
     {
-        uint64_t m = __ballot(comp < tau);
         while (m) {
             uint32_t l = (uint32_t)__builtin_ctzll(m);
             m &= m - 1;
@@ -108,6 +198,25 @@ struct WaveTopKReg {
                 insert(c);
         }
     }
+    __device__ __forceinline__ void offer(uint64_t comp) { offer_some(__ballot(comp < tau), comp); }
+    // 64 keys in descending order (lane l: the (l+1)-th largest): the list becomes the 64 smallest of the union.
+    // (All 64 lanes of e stay sorted, entries beyond k included: min(ascending, descending) is bitonic.)
+    __device__ __forceinline__ void merge_desc(uint64_t r)
+    {
+        e = bitonic_merge<64, false>(min_u64(e, r));
+        tau = readlane64(e, k - 1);
+    }
+    // offer() for a vector that may hold many keys below the k-th best (a wave's first row-block, list heads)
+    __device__ __forceinline__ void offer_dense(uint64_t comp)
+    {
+        const uint64_t m = __ballot(comp < tau);
+        if ((uint32_t)__popcll(m) > kBulkOfferMin) // wave-uniform
+            merge_desc(wave_sort_desc(comp));
+        else
+            offer_some(m, comp);
+    }
+    // merge a published list (ascending, kSentinel padded to 64 entries: spill())
+    __device__ __forceinline__ void merge_list(const uint64_t *other) { merge_desc(other[63u - lane_id()]); }
     // entry i (i < 64) for lane i
     __device__ __forceinline__ uint64_t mine() const { return e; }
     __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
@@ -154,9 +263,8 @@ struct WaveTopKReg2 {
         }
         tau = k <= 64u ? readlane64(e0, k - 1u) : readlane64(e1, k - 65u);
     }
-    __device__ __forceinline__ void offer(uint64_t comp)
+    __device__ __forceinline__ void offer_some(uint64_t m, uint64_t comp)
     {
-        uint64_t m = __ballot(comp < tau);
         while (m) {
             uint32_t l = (uint32_t)__builtin_ctzll(m);
             m &= m - 1;
@@ -164,6 +272,30 @@ struct WaveTopKReg2 {
             if (c < tau)
                 insert(c);
         }
+    }
+    __device__ __forceinline__ void offer(uint64_t comp) { offer_some(__ballot(comp < tau), comp); }
+    // 128 keys in descending order (r_lo lane l: the (l+1)-th largest, r_hi: the (l+65)-th): the list becomes the
+    // 128 smallest of the union -- elementwise min with the ascending list is bitonic over 128, one exchange between
+    // the registers and a 64-merge of each sorts it
+    __device__ __forceinline__ void merge_desc(uint64_t r_lo, uint64_t r_hi)
+    {
+        const uint64_t lo = min_u64(e0, r_lo), hi = min_u64(e1, r_hi);
+        e0 = bitonic_merge<64, false>(min_u64(lo, hi));
+        e1 = bitonic_merge<64, false>(max_u64(lo, hi));
+        tau = k <= 64u ? readlane64(e0, k - 1u) : readlane64(e1, k - 65u);
+    }
+    __device__ __forceinline__ void offer_dense(uint64_t comp)
+    {
+        const uint64_t m = __ballot(comp < tau);
+        if ((uint32_t)__popcll(m) > kBulkOfferMin) // wave-uniform
+            merge_desc(kSentinel, wave_sort_desc(comp));
+        else
+            offer_some(m, comp);
+    }
+    // merge a published list (ascending, kSentinel padded to 128 entries: spill())
+    __device__ __forceinline__ void merge_list(const uint64_t *other)
+    {
+        merge_desc(other[127u - lane_id()], other[63u - lane_id()]);
     }
     __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
     {
@@ -238,6 +370,15 @@ struct WaveTopKLds {
                 insert(c);
         }
     }
+    __device__ __forceinline__ void offer_dense(uint64_t comp) { offer(comp); }
+    // merge another wave's list of k entries (ascending)
+    __device__ __forceinline__ void merge_list(const uint64_t *other)
+    {
+        for (uint32_t base = 0; base < k; base += 64) {
+            const uint32_t idx = base + lane_id();
+            offer(idx < k ? other[idx] : kSentinel);
+        }
+    }
     __device__ __forceinline__ void store(uint64_t *dst, size_t stride = 1) const
     {
         for (uint32_t i = lane_id(); i < k; i += 64)
@@ -254,6 +395,8 @@ struct WaveWriteAll {
     uint64_t tau;
     __device__ __forceinline__ void init(uint32_t, uint64_t *) { tau = kSentinel; }
     __device__ __forceinline__ void offer(uint64_t) {}
+    __device__ __forceinline__ void offer_dense(uint64_t) {}
+    __device__ __forceinline__ void merge_list(const uint64_t *) {}
     __device__ __forceinline__ void store(uint64_t *, size_t = 1) const {}
     __device__ __forceinline__ void spill(uint64_t *) const {}
 };

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void scan_i8dom_kernel(const uint4 *__restr
             const float dist = f_div(f_sqrt((float)S), scale);
             comp = ((uint64_t)dist_key(dist) << 32) | row;
         }
-        top.offer(comp);
+        top.offer_dense(comp);
     }
 
     // fold the 4 waves' lists into wave 0's, one list per workgroup to HBM ([q][j][list])
@@ -125,13 +125,8 @@ __global__ __launch_bounds__(kBlock) void scan_i8dom_kernel(const uint4 *__restr
     top.spill(mine);
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w) {
-            const uint64_t *other = dyn_lds + (size_t)w * list_stride;
-            for (uint32_t base = 0; base < k; base += 64) {
-                const uint32_t idx = base + lane;
-                top.offer(idx < k ? other[idx] : kSentinel);
-            }
-        }
+        for (int w = 1; w < kWavesPerBlock; ++w)
+            top.merge_list(dyn_lds + (size_t)w * list_stride);
         top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
     }
 }

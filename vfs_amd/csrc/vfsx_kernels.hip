@@ -113,6 +113,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
             if (TopK::kWriteAll) { // `lists` is the key buffer [nq][64 n_rowblocks]: one coalesced 512 B store per wave
                 if (q0 + n < nq)
                     lists[(size_t)(q0 + n) * n_rowblocks * 64u + row] = comp;
+            } else if (NQ == 1) {
+                top[n].offer_dense(comp); // (a wave's first row-block: 64 keys into an empty list)
             } else {
                 top[n].offer(comp);
             }
@@ -201,14 +203,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     if (wave == 0) {
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
-            for (int w = 1; w < kWavesPerBlock; ++w) {
-                const uint64_t *other = dyn_lds + ((size_t)w * NQ + n) * list_stride;
-                for (uint32_t base = 0; base < k; base += 64) {
-                    uint32_t idx = base + lane;
-                    uint64_t comp = idx < k ? other[idx] : kSentinel;
-                    top[n].offer(comp);
-                }
-            }
+            for (int w = 1; w < kWavesPerBlock; ++w)
+                top[n].merge_list(dyn_lds + ((size_t)w * NQ + n) * list_stride);
             // column-major: entry j of every list is contiguous ([q][j][list]) for the select walk
             if (q0 + n < nq)
                 top[n].store(lists + (size_t)(q0 + n) * n_lists * k + blockIdx.x, n_lists);
@@ -296,7 +292,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void scan_i8w_kernel(
                 dist = f_sub(1.0f, f_div(acc.a, f_mul(qn, row_norms[row]))); // rank.rs:299
             comp = ((uint64_t)dist_key(dist) << 32) | row;
         }
-        top.offer(comp);
+        top.offer_dense(comp);
     };
 
     uint32_t blk = blockIdx.x * kWideWaves + wave;
@@ -316,7 +312,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void scan_i8w_kernel(
     __syncthreads();
     if (wave == 0) {
         for (int w = 1; w < kWideWaves; ++w)
-            top.offer(lane < k ? dyn_lds[(size_t)w * 64u + lane] : kSentinel);
+            top.merge_list(dyn_lds + (size_t)w * 64u);
         top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
     }
 }
@@ -356,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
                 break;
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u)
-                top.offer(c[u]);
+                top.offer_dense(c[u]); // (the heads of 64 lists meet an empty list: sorted and merged, not inserted)
             alive = alive && (c[3] < top.tau);
             if (__ballot(alive) == 0)
                 break;
@@ -367,11 +363,21 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
     __syncthreads();
     top.spill(mine);
     __syncthreads();
+    if (TopK::kInRegisters) {
+        // sorted register lists: a merge tree over the waves, 6 (k <= 64) or 13 compare-exchange stages per level
+        for (uint32_t s = 1; s < (uint32_t)WAVES; s <<= 1) {
+            if ((wave & (2u * s - 1u)) == 0u && wave + s < (uint32_t)WAVES) {
+                top.merge_list(dyn_lds + (wave + s) * list_stride);
+                top.spill(mine); // read by the next level only: this level reads the slots of waves that do not merge
+            }
+            __syncthreads();
+        }
+    }
     if (wave == 0) {
-        // lane w walks wave w's (ascending) list the same way
-        bool alive = lane >= 1 && lane < (uint32_t)WAVES;
+        // lists in LDS: lane w walks wave w's (ascending) list while it still beats the k-th best
+        bool alive = !TopK::kInRegisters && lane >= 1 && lane < (uint32_t)WAVES;
         const uint64_t *other = dyn_lds + (alive ? lane : 0u) * list_stride;
-        for (uint32_t j = 0; j < k; ++j) {
+        for (uint32_t j = 0; !TopK::kInRegisters && j < k; ++j) {
             uint64_t c = alive ? other[j] : kSentinel;
             if (__ballot(c < top.tau) == 0)
                 break;

@@ -1069,16 +1069,25 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
             sc[j] = in ? src[(size_t)j * n_lists + list] : ninf;
 #pragma unroll
         for (uint32_t j = 0; j < kListDepth; ++j)
-            top.offer((sc[j] == ninf) ? kSentinel : (((uint64_t)dist_key(-sc[j]) << 32) | list));
+            top.offer_dense((sc[j] == ninf) ? kSentinel : (((uint64_t)dist_key(-sc[j]) << 32) | list));
     }
     uint64_t *mine = dyn_lds + wave * list_stride;
     __syncthreads();
     top.spill(mine);
     __syncthreads();
+    if (TopK::kInRegisters) { // merge tree over the waves' sorted register lists (as in select_kernel)
+        for (uint32_t s = 1; s < (uint32_t)WAVES; s <<= 1) {
+            if ((wave & (2u * s - 1u)) == 0u && wave + s < (uint32_t)WAVES) {
+                top.merge_list(dyn_lds + (wave + s) * list_stride);
+                top.spill(mine);
+            }
+            __syncthreads();
+        }
+    }
     if (wave == 0) {
-        bool alive = lane >= 1 && lane < (uint32_t)WAVES;
+        bool alive = !TopK::kInRegisters && lane >= 1 && lane < (uint32_t)WAVES;
         const uint64_t *other = dyn_lds + (alive ? lane : 0u) * list_stride;
-        for (uint32_t j = 0; j < kp; ++j) {
+        for (uint32_t j = 0; !TopK::kInRegisters && j < kp; ++j) {
             uint64_t c = alive ? other[j] : kSentinel;
             if (__ballot(c < top.tau) == 0)
                 break;
@@ -1184,7 +1193,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
             }
             comp = ((uint64_t)dist_key(dist) << 32) | row;
         }
-        top.offer(comp);
+        top.offer_dense(comp); // 64 exact distances into an empty list
     }
 
     uint64_t *mine = dyn_lds + wave * list_stride;
@@ -1192,14 +1201,8 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     top.spill(mine); // (kSentinel padded to 64 / 128 entries; a no-op for a list that lives in LDS)
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w) {
-            const uint64_t *other = dyn_lds + w * list_stride;
-            for (uint32_t base = 0; base < k; base += 64) {
-                uint32_t idx = base + lane;
-                uint64_t comp = idx < k ? other[idx] : kSentinel;
-                top.offer(comp);
-            }
-        }
+        for (int w = 1; w < kWavesPerBlock; ++w)
+            top.merge_list(dyn_lds + w * list_stride);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         top.store(mine);
