@@ -113,10 +113,8 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
             if (TopK::kWriteAll) { // `lists` is the key buffer [nq][64 n_rowblocks]: one coalesced 512 B store per wave
                 if (q0 + n < nq)
                     lists[(size_t)(q0 + n) * n_rowblocks * 64u + row] = comp;
-            } else if (NQ == 1) {
-                top[n].offer_dense(comp); // (a wave's first row-block: 64 keys into an empty list)
             } else {
-                top[n].offer(comp);
+                top[n].offer_dense(comp); // (a wave's first row-block: 64 keys into an empty list)
             }
         }
     };
