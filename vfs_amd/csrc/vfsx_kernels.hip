@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
     if (TopK::kInRegisters) {
         // sorted register lists: a merge tree over the waves, 6 (k <= 64) or 13 compare-exchange stages per level
         for (uint32_t s = 1; s < (uint32_t)WAVES; s <<= 1) {
-            if ((wave & (2u * s - 1u)) == 0u && wave + s < (uint32_t)WAVES) {
+            if ((wave & (2u * s - 1u)) == 0u && wave + s < (uint32_t)WAVES &&
+                (wave + s) * 64u < n_lists) { // (a partner wave without lists has nothing to merge)
                 top.merge_list(dyn_lds + (wave + s) * list_stride);
                 top.spill(mine); // read by the next level only: this level reads the slots of waves that do not merge
             }

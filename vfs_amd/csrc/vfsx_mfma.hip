@@ -1077,7 +1077,8 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
     __syncthreads();
     if (TopK::kInRegisters) { // merge tree over the waves' sorted register lists (as in select_kernel)
         for (uint32_t s = 1; s < (uint32_t)WAVES; s <<= 1) {
-            if ((wave & (2u * s - 1u)) == 0u && wave + s < (uint32_t)WAVES) {
+            if ((wave & (2u * s - 1u)) == 0u && wave + s < (uint32_t)WAVES &&
+                (wave + s) * 64u < n_lists) { // (a partner wave without lists has nothing to merge)
                 top.merge_list(dyn_lds + (wave + s) * list_stride);
                 top.spill(mine);
             }
