@@ -199,6 +199,7 @@ struct WaveTopKReg {
         }
     }
     __device__ __forceinline__ void offer(uint64_t comp) { offer_some(__ballot(comp < tau), comp); }
+    __device__ __forceinline__ uint64_t rank(uint32_t i) const { return readlane64(e, i); } // i-th smallest, i < 64
     // 64 keys in descending order (lane l: the (l+1)-th largest): the list becomes the 64 smallest of the union.
     // (All 64 lanes of e stay sorted, entries beyond k included: min(ascending, descending) is bitonic.)
     __device__ __forceinline__ void merge_desc(uint64_t r)
@@ -274,6 +275,7 @@ struct WaveTopKReg2 {
         }
     }
     __device__ __forceinline__ void offer(uint64_t comp) { offer_some(__ballot(comp < tau), comp); }
+    __device__ __forceinline__ uint64_t rank(uint32_t i) const { return readlane64(e0, i); } // i-th smallest, i < 64
     // 128 keys in descending order (r_lo lane l: the (l+1)-th largest, r_hi: the (l+65)-th): the list becomes the
     // 128 smallest of the union -- elementwise min with the ascending list is bitonic over 128, one exchange between
     // the registers and a 64-merge of each sorts it
@@ -371,6 +373,7 @@ struct WaveTopKLds {
         }
     }
     __device__ __forceinline__ void offer_dense(uint64_t comp) { offer(comp); }
+    __device__ __forceinline__ uint64_t rank(uint32_t i) const { return L[i]; }
     // merge another wave's list of k entries (ascending)
     __device__ __forceinline__ void merge_list(const uint64_t *other)
     {
@@ -396,6 +399,7 @@ struct WaveWriteAll {
     __device__ __forceinline__ void init(uint32_t, uint64_t *) { tau = kSentinel; }
     __device__ __forceinline__ void offer(uint64_t) {}
     __device__ __forceinline__ void offer_dense(uint64_t) {}
+    __device__ __forceinline__ uint64_t rank(uint32_t) const { return kSentinel; }
     __device__ __forceinline__ void merge_list(const uint64_t *) {}
     __device__ __forceinline__ void store(uint64_t *, size_t = 1) const {}
     __device__ __forceinline__ void spill(uint64_t *) const {}

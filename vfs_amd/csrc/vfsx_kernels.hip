@@ -337,23 +337,57 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
 
     TopK top;
     top.init(k, dyn_lds + wave * list_stride);
-    for (uint32_t lbase = wave * 64u; lbase < n_lists; lbase += BLOCK) { // wave-uniform
+    // `bound`: an upper bound of the k-th smallest key of ALL lists, known after the heads -- a wave alone only
+    // learns the k-th smallest of ITS 64 lists, which prunes nothing while k is of the order of 64 (k = 100: a wave
+    // needs two columns just to fill its list).  With `full` waves holding 64 lists each and m = ceil(k / full),
+    // the m smallest heads of every such wave are >= k keys, all <= the largest of those m-th heads: that maximum
+    // bounds the global k-th smallest.  One LDS atomic per wave; entries >= bound are dropped before they are offered.
+    __shared__ unsigned long long s_bound;
+    uint64_t bound = kSentinel;
+    uint32_t lbase = wave * 64u, j0 = 0;
+    bool alive0 = true;
+    if (TopK::kInRegisters) { // (compile-time: every wave takes the barriers)
+        if (threadIdx.x == 0)
+            s_bound = 0ull;
+        __syncthreads();
+        const uint32_t full = n_lists / 64u, m = full ? (k + full - 1u) / full : 65u;
         const uint32_t list = lbase + lane;
-        bool alive = list < n_lists;
-        for (uint32_t j = 0; j < k; j += 4) {
+        const bool in = list < n_lists;
+        uint64_t c[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            c[u] = (in && u < k) ? src[(size_t)u * n_lists + list] : kSentinel;
+        top.offer_dense(c[0]); // the heads of 64 lists meet an empty list: sorted and merged, not inserted
+        if (m <= 64u && wave < full && lane == 0u)
+            atomicMax(&s_bound, (unsigned long long)top.rank(m - 1u));
+        __syncthreads();
+        if (m <= 64u)
+            bound = s_bound;
+#pragma unroll
+        for (uint32_t u = 1; u < 4u; ++u)
+            top.offer_dense(c[u] < bound ? c[u] : kSentinel);
+        alive0 = in && c[3] < bound && c[3] < top.tau;
+        j0 = 4;
+    }
+    for (; lbase < n_lists; lbase += BLOCK, j0 = 0, alive0 = true) { // wave-uniform
+        const uint32_t list = lbase + lane;
+        bool alive = alive0 && list < n_lists;
+        for (uint32_t j = j0; j < k; j += 4) {
+            if (__ballot(alive) == 0)
+                break;
             // four columns per round trip (the lists were just written by other CUs: every trip is ~2 us)
             uint64_t c[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u)
+            for (uint32_t u = 0; u < 4u; ++u) {
                 c[u] = (alive && j + u < k) ? src[(size_t)(j + u) * n_lists + list] : kSentinel;
+                c[u] = c[u] < bound ? c[u] : kSentinel;
+            }
             if (__ballot(c[0] < top.tau) == 0)
                 break;
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u)
-                top.offer_dense(c[u]); // (the heads of 64 lists meet an empty list: sorted and merged, not inserted)
+                top.offer_dense(c[u]);
             alive = alive && (c[3] < top.tau);
-            if (__ballot(alive) == 0)
-                break;
         }
     }
 
