@@ -1060,8 +1060,13 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
 
     TopK top;
     top.init(kp, dyn_lds + wave * list_stride);
-    for (uint32_t lbase = wave * 64u; lbase < n_lists; lbase += BLOCK) {
-        const uint32_t list = lbase + lane;
+    // `bound`: an upper bound of the kp-th best key of all lists from the heads of the first 64 * WAVES lists, as in
+    // select_kernel (vfsx_kernels.hip) -- the second and third entries of the lists, and every later head, are
+    // dropped against it before they are sorted
+    __shared__ unsigned long long s_bound;
+    uint64_t bound = kSentinel;
+    uint32_t lbase = wave * 64u;
+    auto load3 = [&](uint32_t list, uint64_t(&comp)[kListDepth]) {
         const bool in = list < n_lists;
         float sc[kListDepth];
 #pragma unroll
@@ -1069,7 +1074,32 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
             sc[j] = in ? src[(size_t)j * n_lists + list] : ninf;
 #pragma unroll
         for (uint32_t j = 0; j < kListDepth; ++j)
-            top.offer_dense((sc[j] == ninf) ? kSentinel : (((uint64_t)dist_key(-sc[j]) << 32) | list));
+            comp[j] = (sc[j] == ninf) ? kSentinel : (((uint64_t)dist_key(-sc[j]) << 32) | list);
+    };
+    if (TopK::kInRegisters) { // (compile-time: every wave takes the barriers)
+        if (threadIdx.x == 0)
+            s_bound = 0ull;
+        __syncthreads();
+        const uint32_t full = min(n_lists / 64u, (uint32_t)WAVES), m = full ? (kp + full - 1u) / full : 65u;
+        uint64_t comp[kListDepth];
+        load3(lbase + lane, comp);
+        top.offer_dense(comp[0]);
+        if (m <= 64u && wave < full && lane == 0u)
+            atomicMax(&s_bound, (unsigned long long)top.rank(m - 1u));
+        __syncthreads();
+        if (m <= 64u)
+            bound = s_bound;
+#pragma unroll
+        for (uint32_t j = 1; j < kListDepth; ++j)
+            top.offer_dense(comp[j] < bound ? comp[j] : kSentinel);
+        lbase += BLOCK;
+    }
+    for (; lbase < n_lists; lbase += BLOCK) {
+        uint64_t comp[kListDepth];
+        load3(lbase + lane, comp);
+#pragma unroll
+        for (uint32_t j = 0; j < kListDepth; ++j)
+            top.offer_dense(comp[j] < bound ? comp[j] : kSentinel);
     }
     uint64_t *mine = dyn_lds + wave * list_stride;
     __syncthreads();
