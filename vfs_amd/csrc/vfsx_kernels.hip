@@ -198,11 +198,19 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     for (int n = 0; n < NQ; ++n)
         top[n].spill(dyn_lds + ((size_t)wave * NQ + n) * list_stride); // (a no-op for lists that live in LDS)
     __syncthreads();
+    for (uint32_t s = 1; s < (uint32_t)kWavesPerBlock; s <<= 1) { // merge tree: wave 2 takes 3's lists while 0 takes 1's
+        if ((wave & (2u * s - 1u)) == 0u) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                top[n].merge_list(dyn_lds + ((size_t)(wave + s) * NQ + n) * list_stride);
+                top[n].spill(dyn_lds + ((size_t)wave * NQ + n) * list_stride);
+            }
+        }
+        __syncthreads();
+    }
     if (wave == 0) {
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
-            for (int w = 1; w < kWavesPerBlock; ++w)
-                top[n].merge_list(dyn_lds + ((size_t)w * NQ + n) * list_stride);
             // column-major: entry j of every list is contiguous ([q][j][list]) for the select walk
             if (q0 + n < nq)
                 top[n].store(lists + (size_t)(q0 + n) * n_lists * k + blockIdx.x, n_lists);
@@ -308,11 +316,15 @@ __global__ __launch_bounds__(64 * kWideWaves) void scan_i8w_kernel(
     uint64_t *mine = dyn_lds + (size_t)wave * 64u;
     top.spill(mine);
     __syncthreads();
-    if (wave == 0) {
-        for (int w = 1; w < kWideWaves; ++w)
-            top.merge_list(dyn_lds + (size_t)w * 64u);
-        top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
+    for (uint32_t s = 1; s < (uint32_t)kWideWaves; s <<= 1) { // merge tree: 4 levels of 6 stages instead of 15 merges by wave 0
+        if ((wave & (2u * s - 1u)) == 0u) {
+            top.merge_list(dyn_lds + (size_t)(wave + s) * 64u);
+            top.spill(mine); // read at the next level; this level reads the rows of waves that do not merge
+        }
+        __syncthreads();
     }
+    if (wave == 0)
+        top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
 }
 
 // ---- select: merge the per-workgroup lists of one query, emit hits ----------------
