@@ -124,11 +124,15 @@ __global__ __launch_bounds__(kBlock) void scan_i8dom_kernel(const uint4 *__restr
     uint64_t *mine = dyn_lds + (size_t)wave * list_stride;
     top.spill(mine);
     __syncthreads();
-    if (wave == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w)
-            top.merge_list(dyn_lds + (size_t)w * list_stride);
-        top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
+    for (uint32_t s = 1; s < (uint32_t)kWavesPerBlock; s <<= 1) { // merge tree (as in scan_kernel)
+        if ((wave & (2u * s - 1u)) == 0u) {
+            top.merge_list(dyn_lds + (size_t)(wave + s) * list_stride);
+            top.spill(mine);
+        }
+        __syncthreads();
     }
+    if (wave == 0)
+        top.store(lists + (size_t)blockIdx.y * n_lists * k + blockIdx.x, n_lists);
 }
 
 template <typename TopK>
