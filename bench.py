@@ -58,10 +58,17 @@ WORKLOADS = {
     "c4eauto": (10_000_000, 1024, False, 0, 4096, "C4 Euclidean with the library's own choice of operand (int8 mirror)"),
     "c4i8": (10_000_000, 1024, True, 1, 4096, "4096-query batch x 10Mx1024 int8 QuantizedVector Cosine: int8 MFMA over the "
                                               "rb64 corpus itself (no mirror) + fused top-k, exact f32 re-score"),
+    "c2m": (1_000_000, 768, False, 1, 256, "C2 1Mx768 f32 Cosine exact top-10, ONE query per call, with the opt-in int8 "
+                                           "mirror (+1 B/element): int8 MFMA prefilter over the mirror, exact f32 "
+                                           "re-score + safety check, exact scan for flagged queries; same results as c2"),
+    "c5m": (12_500_000, 768, False, 0, 32, "C5 shard 12.5Mx768 f32 Euclidean, ONE query per call, with the opt-in int8 "
+                                           "mirror (+1 B/element); same results as c5"),
     "c3b": (10_000_000, 128, True, 0, 4096, "C3 in batches: 4096 queries x 10Mx128 int8 QuantizedVector Euclidean, int8 "
                                             "MFMA over the rb64 corpus + upper-bound epilogue, exact f32 re-score"),
 }
 MFMA_WORKLOADS = ("c4", "c4e", "c4auto", "c4eauto", "c4i8", "c3b")
+# single queries through the mirror: on an f32 store the prefilter reads 1 B per element where the exact scan reads 4
+MIRROR_SINGLE_WORKLOADS = ("c2m", "c5m")
 METRIC_NAMES = ["euclidean", "cosine", "simd_euclidean", "simd_cosine", "euclidean_i8_domain"]
 
 
@@ -124,6 +131,7 @@ def main(argv=None) -> int:
     workload = args.workload or ("c2" if world == 1 else "c5")
     rows, dim, quantize, metric, qps_default, label = WORKLOADS[workload]
     mfma = workload in MFMA_WORKLOADS
+    mirror_single = workload in MIRROR_SINGLE_WORKLOADS
     if mfma:
         args.mode = "batch"
         if args.steps == 40:  # ~2 s of timed region at 40-70 ms per 4096-query batch
@@ -202,7 +210,7 @@ def main(argv=None) -> int:
     corpus = vfs_amd.Corpus(dim, quantize=quantize, capacity_rows=rows, device=local_rank)
     corpus.fill_synthetic(synth.CORPUS_SEED, rows, row0=rank * rows, id0=1 + rank * rows)
     corpus.set_row_base(rank * rows)
-    if mfma:
+    if mfma or mirror_single:
         corpus.enable_mfma(True, mirror="bf16" if workload in ("c4", "c4e") else "auto")
         mirror_kind, mirror_rx = corpus.mfma_mirror()
 
@@ -390,6 +398,31 @@ def main(argv=None) -> int:
                         "bf16 MFMA prefilter + f32 exact re-score")
         out["mfma_operand"] = {"kind": mirror_kind, "measured_row_residual": round(mirror_rx, 6),
                                "after_run": corpus.mfma_mirror()[0]}
+
+    if mirror_single:
+        # the profiled kernel is the small-batch prefilter: HBM-bound on the MIRROR's bytes (1 B per element, int8;
+        # 2 B, bf16), not on the store's 4 B per element
+        mq, mf = corpus.mfma_stats()
+        m_elem = 1 if mirror_kind == "int8" else 2
+        m_bytes = rows * dim * m_elem
+        m_ach = m_bytes / (avg_ms * 1e-3) / 1e9
+        out["metric"] = (f"exact top-{k} QPS (one query per call; int8-mirror prefilter on the matrix cores + exact f32 "
+                         "re-score; queries/s against the whole row-sharded corpus)")
+        out["dtype"] = "int8 MFMA (i32 accumulate) prefilter + f32 exact re-score" if m_elem == 1 else \
+                       "bf16 MFMA prefilter + f32 exact re-score"
+        out["roofline"] = {"bound": "hbm", "achieved": round(m_ach * world, 1), "peak": HBM_PEAK_GBPS * world,
+                           "unit": "GB/s", "frac": round(m_ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                           "kernel": "mfma_prefilter_skinny_kernel", "avg_kernel_ms": round(avg_ms, 5),
+                           "algorithmic_bytes_per_launch": m_bytes, "launches_timed": int(scan_launches),
+                           "what": "average prefilter launch (HIP events on its stream) over the mirror's bytes"}
+        for key in ("hbm_gbps_aggregate", "hbm_frac_of_aggregate_peak", "shard_scans_per_s"):
+            out.pop(key, None)  # those describe the 4 B per element scan
+        out["mfma_queries"] = int(mq)
+        out["mfma_fallback_queries"] = int(mf)
+        out["mfma_operand"] = {"kind": mirror_kind, "measured_row_residual": round(mirror_rx, 6),
+                               "after_run": corpus.mfma_mirror()[0]}
+        if latency:
+            latency["what"] = "device time per query (prefilter + select + re-score [+ exact scan if flagged]), back-to-back"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, rows, dim, quantize, metric, k)

@@ -154,6 +154,39 @@ def test_c4_10m_x1024_mfma_batch_equals_exact_scan(oracle):
     c.close()
 
 
+def test_c2_single_queries_through_the_mirror_equal_exact_scan(oracle):
+    """C2 size, f32 store with the (opt-in) mirror: from 4e8 elements on even ONE query per call goes through the
+    matrix-core path (the prefilter reads the 1 B per element mirror, the scan 4 B per element; vfsx_api.cpp
+    mfma_min_batch_for).  Every such query must equal the exact scan bit for bit, for both mirrors, Cosine and
+    Euclidean, k = 10 and 100; a small corpus keeps single queries on the exact scan."""
+    import vfs_amd
+    n, d = 1_000_000, 768
+    c = vfs_amd.Corpus(d, capacity_rows=n)
+    c.fill_synthetic(SEED_C, n)
+    queries = oracle.synth_f32(SEED_Q, 0, 12, d)
+    for metric, k in ((1, 10), (0, 10), (1, 100)):
+        c.enable_mfma(False)
+        ids_e, dist_e, _ = c.search_batch(queries, k, metric)
+        for mirror in ("int8", "bf16"):
+            c.enable_mfma(True, mirror=mirror)
+            c.mfma_stats(reset=True)
+            for i in range(len(queries)):
+                ids_m, dist_m, cnt_m = c.search_batch(queries[i:i + 1], k, metric)
+                assert (ids_m[0] == ids_e[i]).all() and (bits(dist_m[0]) == bits(dist_e[i])).all() and cnt_m[0] == k
+            mq, fb = c.mfma_stats()
+            if k == 10:  # (k = 100 on random 768-d rows: hundreds of rows within the margin of the 100th, most
+                #          queries go back to the exact scan and the path backs off -- results are what counts there)
+                assert mq == len(queries) and fb <= 2, (mirror, metric, k, mq, fb)
+    c.close()
+    small = vfs_amd.Corpus(128, capacity_rows=100_000)
+    small.fill_synthetic(SEED_C, 100_000)
+    small.enable_mfma(True)
+    small.mfma_stats(reset=True)
+    small.search_batch(oracle.synth_f32(SEED_Q, 0, 1, 128), 10, 1)
+    assert small.mfma_stats() == (0, 0)  # 1.28e7 elements: the exact scan
+    small.close()
+
+
 def test_c4_10m_x1024_int8_store_mfma_batch_equals_exact_scan(oracle):
     """C4's shape on an int8 store (10 GB): the int8 MFMA prefilter reads the rb64 corpus itself.  Sampled queries of
     a 4096-query batch equal the exact scan, Cosine and Euclidean; a winner's distance equals the oracle's on the

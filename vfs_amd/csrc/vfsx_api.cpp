@@ -193,7 +193,7 @@ struct vfsx_corpus {
     int mirror_kind = kMirrorI8;
     int mirror_pref = 0; // 0 auto, 1 bf16, 2 int8 (vfsx_corpus_enable_mfma's argument - 1, or VFSX_MFMA_MIRROR)
     float mirror_rx = 0.0f;
-    uint32_t mfma_min_batch = 4;
+    uint32_t mfma_min_batch = 4;  // 0 = by store type and size (mfma_min_batch_for)
     uint32_t mfma_kp_override = 0; // VFSX_MFMA_KP: first-pass candidates per query (0 = by k)
     DeviceBuf<uint8_t> q_mirror;
     DeviceBuf<int> q_bad, q_flags;
@@ -205,6 +205,7 @@ struct vfsx_corpus {
     // was wasted work; skip it for the next `mfma_backoff` batches, doubling the pause while it keeps
     // happening (1, 3, 7, ... 63 batches), and probe again afterwards
     uint32_t mfma_backoff = 0, mfma_backoff_next = 0;
+    uint32_t mirror_win_queries = 0, mirror_win_flagged = 0; // auto mirror choice: queries / margin failures seen
 
     // profiling
     bool profiling = false;
@@ -854,16 +855,24 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         for (uint32_t q = 0; q < nq; ++q)
             flagged += c->h_flags[q] ? 1u : 0u;
         bool to_bf16 = false;
-        if (mirror_is_i8(c) && c->mirror_pref == 0 && flagged * 8u > nq) {
+        if (mirror_is_i8(c) && c->mirror_pref == 0) {
             // auto: does the int8 mirror's wider margin send too many of this data's queries back?  (Queries the
             // path never took -- zero / out-of-range norms -- are flagged too and say nothing about the mirror.)
-            std::vector<int> bad(nq);
-            HIP_CHECK(hipMemcpyAsync(bad.data(), c->q_bad.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            // Judged over windows of >= 64 queries, so that one flagged single-query call decides nothing.
             uint32_t by_margin = 0;
-            for (uint32_t q = 0; q < nq; ++q)
-                by_margin += (c->h_flags[q] && !bad[q]) ? 1u : 0u;
-            to_bf16 = by_margin * 8u > nq;
+            if (flagged) {
+                std::vector<int> bad(nq);
+                HIP_CHECK(hipMemcpyAsync(bad.data(), c->q_bad.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                for (uint32_t q = 0; q < nq; ++q)
+                    by_margin += (c->h_flags[q] && !bad[q]) ? 1u : 0u;
+            }
+            c->mirror_win_queries += nq;
+            c->mirror_win_flagged += by_margin;
+            if (c->mirror_win_queries >= 64u) {
+                to_bf16 = (uint64_t)c->mirror_win_flagged * 8u > c->mirror_win_queries;
+                c->mirror_win_queries = c->mirror_win_flagged = 0;
+            }
         }
         if (to_bf16) { // bf16 mirror from the next batch on (rebuilt by ensure_mirror), for good
             c->mirror_kind = vfsx_corpus::kMirrorBf16;
@@ -920,6 +929,24 @@ void chain_search_stream(vfsx_corpus *c, hipStream_t s)
     c->searched = true;
 }
 
+// Smallest batch the matrix-core path takes (profiles/r02/batch_crossover.txt).  From 4 queries on it wins on every
+// shape measured.  Below that the exact scan shares one pass among the queries -- but on an f32 store the prefilter
+// reads the MIRROR, 1 B (int8) or 2 B (bf16) per element where the scan reads 4: once the bytes saved outweigh the
+// path's fixed ~120 us (launch chain, re-score gather, flag read-back) even a single query is faster through it
+// (1M x 768: 0.243 vs 0.449 ms; 12.5M x 768: 1.56 vs 5.48 ms) -- from 4e8 elements on with the int8 mirror, 6e8 with
+// the bf16 one.  VFSX_MFMA_MIN_BATCH overrides.
+uint32_t mfma_min_batch_for(const vfsx_corpus *c)
+{
+    if (c->mfma_min_batch)
+        return c->mfma_min_batch;
+    if (c->dtype == VFSX_F32) {
+        const uint64_t elems = c->n_rows * (uint64_t)c->dim;
+        if (elems >= (mirror_is_i8(c) ? 400000000ull : 600000000ull))
+            return 1;
+    }
+    return 4;
+}
+
 void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
                         vfsx_hit *d_hits, hipStream_t s)
 {
@@ -934,7 +961,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     chain_search_stream(c, s);
     // the reference's four metrics; the integer-domain extension has its own kernel
     const bool metric_ok = metric != VFSX_EUCLIDEAN_I8DOMAIN;
-    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= c->mfma_min_batch && k <= vfsx::kMfmaMaxK && c->dim <= vfsx::kMfmaMaxDim &&
+    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= mfma_min_batch_for(c) && k <= vfsx::kMfmaMaxK && c->dim <= vfsx::kMfmaMaxDim &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok && c->mfma_backoff > 0) {
         --c->mfma_backoff; // see vfsx_corpus::mfma_backoff
@@ -1078,7 +1105,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         c->balanced_grid = env_u64("VFSX_BALANCED_GRID", 1) != 0;
         c->n_cus = (uint32_t)prop.multiProcessorCount;
         c->i8_wide = (uint32_t)std::min<uint64_t>(env_u64("VFSX_I8_WIDE", 3), 3);
-        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 4); // measured crossover (profiles/r02/batch_crossover.txt)
+        c->mfma_min_batch = (uint32_t)env_u64("VFSX_MFMA_MIN_BATCH", 0); // 0: the measured crossovers (mfma_min_batch_for)
         c->mfma_kp_override = (uint32_t)env_u64("VFSX_MFMA_KP", 0);
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
@@ -1336,6 +1363,7 @@ int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
             fail(VFSX_ERR_INVALID_VECTOR, "vfsx_corpus_enable_mfma: enable must be 0 (off), 1 (auto), 2 (bf16 mirror) or 3 (int8 mirror)");
         c->mfma_enabled = enable != 0;
         c->mfma_backoff = c->mfma_backoff_next = 0;
+        c->mirror_win_queries = c->mirror_win_flagged = 0;
         if (!enable) {
             free_mirror(c);
             return;
