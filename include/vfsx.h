@@ -334,9 +334,11 @@ int vfsx_comm_merge_hits(vfsx_comm *comm, const vfsx_hit *d_local, uint32_t nq, 
  * enable: 0 = off, 1 = on (mirror chosen by the library), 2 = on with a bf16 mirror, 3 = on with an int8 mirror.
  * An f32 store gets a mirror the matrix cores multiply: int8 with one scale per row (+1 byte per element, read by
  * v_mfma_i32_32x32x32_i8 at twice the bf16 rate) or bf16 (+2 bytes per element); with 1 the library starts on int8
- * and moves to bf16 for good when the rows' measured quantization residual is large or a batch sends more than 1/8 of
- * its queries back.  An int8 store needs no mirror: its rb64 rows are the int8 operand (+12 bytes per row).
- * Afterwards vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 queries with
+ * and moves to bf16 for good when the rows' measured quantization residual is large or more than 1/8 of the queries
+ * (counted over windows of >= 64) come back.  An int8 store needs no mirror: its rb64 rows are the int8 operand (+12 bytes per row).
+ * Afterwards vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 queries -- on an
+ * f32 store of >= 4e8 elements (6e8 with the bf16 mirror) every call, single queries included: the prefilter reads
+ * the mirror's 1 or 2 bytes per element where the exact scan reads 4 (VFSX_MFMA_MIN_BATCH overrides) -- with
  * k <= 128 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the
  * exact scan) through Q.X^T on MFMA + an exact sequential re-score of the surviving candidates + a bound check built
  * from the measured rounding / quantization residuals, and re-run the exact scan for any query the check cannot
