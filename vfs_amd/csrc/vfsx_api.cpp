@@ -790,8 +790,6 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 
     for (uint32_t q0 = 0; q0 < nq; q0 += q_round) {
         const uint32_t qn = std::min(q_round, nq - q0);
-        const uint32_t qn_pad = (qn + 255u) / 256u * 256u;
-        HIP_CHECK(hipMemsetAsync(c->q_mirror.p, 0, (size_t)qn_pad * g.k_pad * qm_elem, s));
         if (i8)
             HIP_CHECK(vfsx::launch_mfma_query_prep_i8(d_queries + (size_t)q0 * c->dim, qn, c->dim, c->q_mirror.p, g.KS,
                                                       c->q_bad.p + q0, c->q_norm.p + q0, c->q_eps.p + q0,

@@ -268,16 +268,21 @@ __global__ void mfma_query_prep_kernel(const float *__restrict__ q_in, uint32_t 
     const float n1 = __builtin_sqrtf(s);
     const bool ok = norm_in_mfma_range(n1);
     float res = 0.0f;
-    if (ok) {
-        for (uint32_t k = lane; k < dim; k += 64) {
-            const uint32_t unit = (q >> 5) * KS + (k >> 4);
-            const uint32_t l2 = (q & 31u) + 32u * ((k & 15u) >> 3);
+    // every k of the padded row is written: zeros beyond dim, and a zero row for a query that takes the exact scan
+    // (rows of queries beyond nq in the last 32-query unit stay as they are: a column of the product only reaches
+    // its own query's scores, and those are never stored)
+    for (uint32_t k = lane; k < KS * 16u; k += 64) {
+        const uint32_t unit = (q >> 5) * KS + (k >> 4);
+        const uint32_t l2 = (q & 31u) + 32u * ((k & 15u) >> 3);
+        uint16_t m = 0;
+        if (ok && k < dim) {
             const float y = src[k] / n1;
-            q_mirror[((size_t)unit * 64u + l2) * 8u + (k & 7u)] = (uint16_t)f32_to_bf16_rne(y);
+            m = (uint16_t)f32_to_bf16_rne(y);
             const float d = bf16_residual(y);
             res += d * d;
         }
-    } // else: the mirror row stays zero (memset by the host) and the query takes the exact scan
+        q_mirror[((size_t)unit * 64u + l2) * 8u + (k & 7u)] = m;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         res += __shfl_xor(res, o, 64);
@@ -319,18 +324,20 @@ __global__ void mfma_query_prep_i8_kernel(const float *__restrict__ q_in, uint32
     const bool ok = norm_in_mfma_range(n1) && mx > 0.0f;
     const float sq = ok ? (mx / n1) / 127.0f : 0.0f; // the largest component maps to +-127 (up to rounding: clamped)
     float res = 0.0f;
-    if (ok) {
-        for (uint32_t k = lane; k < dim; k += 64) {
+    for (uint32_t k = lane; k < KS * 32u; k += 64) { // the whole padded row, as in mfma_query_prep_kernel
+        const uint32_t unit = (q >> 5) * KS + (k >> 5);
+        const uint32_t l2 = (q & 31u) + 32u * ((k & 31u) >> 4);
+        int8_t m = 0;
+        if (ok && k < dim) {
             const float y = src[k] / n1;
             float t = rintf(y / sq);
             t = fminf(fmaxf(t, -127.0f), 127.0f);
-            const uint32_t unit = (q >> 5) * KS + (k >> 5);
-            const uint32_t l2 = (q & 31u) + 32u * ((k & 31u) >> 4);
-            q_mirror[((size_t)unit * 64u + l2) * 16u + (k & 15u)] = (int8_t)(int)t;
+            m = (int8_t)(int)t;
             const float d = y - sq * t; // two roundings of <= 2^-24 |y| each: covered below
             res += d * d;
         }
-    } // else: the mirror row stays zero (memset by the host) and the query takes the exact scan
+        q_mirror[((size_t)unit * 64u + l2) * 16u + (k & 15u)] = m;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         res += __shfl_xor(res, o, 64);
