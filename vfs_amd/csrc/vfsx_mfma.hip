@@ -1333,6 +1333,264 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
         flags[q] = s_flag;
 }
 
+// ---- re-score for small batches: the lanes share a row, one lane adds ---------------------------------------
+// mfma_rescore_kernel gives every candidate row to ONE lane, which walks the row's d elements alone: with a
+// handful of queries that is one busy wave per query on an otherwise idle chip, 40 us (f32, d = 768) of
+// round trips and dependent arithmetic.  Only the ADDITIONS have to be sequential for the result to be the
+// reference's (rank.rs:281-300: a left fold); the products (q_j - x_j)^2 / q_j x_j are independent.  Here a wave
+// takes 4 candidates at a time: its 64 lanes fetch 256 elements of each (f32: lane l chunk l of all four;
+// int8: lane l chunk l & 15 of candidate l >> 4), form the products with the scan's own operations, park them in
+// LDS in element order, and lanes 0..3 fold "their" candidate's 256 products in order (lane 4: the q_j^2 of
+// Cosine).  16 waves per query, kp / 16 candidates each; the next block's loads are in flight during the fold.
+// Same arithmetic, same order => same bits; select, top-k, hits and the safety check as in mfma_rescore_kernel.
+constexpr uint32_t kCoopWaves = 16, kCoopBlockElems = 256;
+
+template <int DTYPE, int METRIC, typename TopK>
+__global__ __launch_bounds__(64 * kCoopWaves) void mfma_rescore_coop_kernel(
+    const uint4 *__restrict__ corpus, const float *__restrict__ row_norms, const float *__restrict__ queries,
+    const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
+    const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
+    uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, const float *__restrict__ q_eps, uint64_t row_base,
+    uint64_t id_base, uint32_t strip_tiles, const float *__restrict__ q_norm, float gamma, int only_flagged,
+    const float *__restrict__ q_scale)
+{
+    if (only_flagged && flags[blockIdx.x] == 0) // second, wider pass: flagged queries only (uniform exit)
+        return;
+    constexpr uint32_t EPC = DTYPE == VFSX_I8 ? 16u : 4u;
+    constexpr uint32_t CPB = kCoopBlockElems / EPC; // chunks per block and candidate: 64 (f32) / 16 (int8)
+    extern __shared__ __align__(16) uint64_t dyn_lds[]; // [16][64 | 128] lists
+    __shared__ __align__(16) float prod[kCoopWaves][5][kCoopBlockElems]; // [wave][candidate 0..3, q^2][element]
+    __shared__ float lut_s[DTYPE == VFSX_I8 ? 256 : 1];
+    __shared__ uint32_t s_list[256];
+    __shared__ float s_dk;
+    __shared__ int s_flag;
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x;
+    const uint32_t list_stride = k > 64u ? 128u : 64u;
+    if (DTYPE == VFSX_I8 && threadIdx.x < 256u)
+        lut_s[threadIdx.x] = lut[threadIdx.x];
+    if (threadIdx.x == 0)
+        s_flag = q_bad[q];
+    __syncthreads();
+    const float *__restrict__ qv = queries + (size_t)q * q_stride;
+
+    // lane t < cpw of wave w owns candidate ci = w * cpw + t (its key, the check, its slot in the wave's offer)
+    const uint32_t cpw = kp / kCoopWaves; // 4 / 8 / 16
+    const uint32_t ci = wave * cpw + lane;
+    const uint64_t comp_a = lane < cpw ? sel[(size_t)q * kp + ci] : kSentinel;
+    const bool valid = comp_a != kSentinel;
+    float score = 0.0f;
+    uint32_t row = 0;
+    if (valid)
+        row = cand_row(comp_a, score, strip_tiles);
+    const bool in_range = valid && row < n_rows;
+    const uint32_t row_safe = in_range ? row : 0u;
+
+    float(*my_prod)[kCoopBlockElems] = prod[wave];
+    const uint32_t n_blocks = (d_chunks + CPB - 1u) / CPB;
+    uint64_t mycomp = kSentinel;
+    float qn = 0.0f;
+    for (uint32_t g = 0; g < cpw; g += 4u) { // (wave-uniform)
+        // the four rows of this group (wave-uniform: SGPRs)
+        uint32_t r4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+            r4[j] = (uint32_t)__builtin_amdgcn_readlane((int)row_safe, (int)(g + j));
+        // what this lane fetches: f32 -- chunk `lane` of each of the four; int8 -- chunk lane & 15 of row lane >> 4
+        const uint32_t my_c = DTYPE == VFSX_I8 ? (lane & 15u) : lane;
+        const uint4 *p[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+            p[j] = corpus + (size_t)(r4[j] >> 6) * d_chunks * 64u + (r4[j] & 63u);
+        const uint4 *p_i8 = (lane >> 4) == 0u ? p[0] : ((lane >> 4) == 1u ? p[1] : ((lane >> 4) == 2u ? p[2] : p[3]));
+        constexpr uint32_t NV = DTYPE == VFSX_I8 ? 1u : 4u;
+        auto fetch = [&](uint32_t blk, uint4(&v)[NV]) __attribute__((always_inline)) {
+            const uint32_t c = blk * CPB + my_c;
+            const bool in = c < d_chunks;
+#pragma unroll
+            for (uint32_t j = 0; j < NV; ++j) {
+                const uint4 *src = DTYPE == VFSX_I8 ? p_i8 : p[j];
+                v[j] = in ? src[(size_t)c * 64u] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        };
+        float acc = 0.0f; // lanes 0..3: the candidates' sums; lane 4: sum q_j^2
+        uint4 cur[NV], nxt[NV];
+        fetch(0, cur);
+        for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+            if (blk + 1u < n_blocks)
+                fetch(blk + 1u, nxt);
+            // products of this block, in element order, into the wave's LDS rows
+            const uint32_t c = blk * CPB + my_c;
+            const bool in = c < d_chunks;
+            float qe[EPC];
+#pragma unroll
+            for (uint32_t i = 0; i < EPC; i += 4u) {
+                const float4 t = in ? *(const float4 *)(qv + (size_t)c * EPC + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                qe[i] = t.x, qe[i + 1] = t.y, qe[i + 2] = t.z, qe[i + 3] = t.w;
+            }
+            if (DTYPE == VFSX_I8) {
+                const uint32_t w[4] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w};
+                float *dst = &my_prod[lane >> 4][my_c * EPC];
+#pragma unroll
+                for (uint32_t i = 0; i < 16u; ++i) {
+                    const float xv = lut_s[(w[i >> 2] >> (8u * (i & 3u))) & 0xffu]; // (q as f32) / scale
+                    float pr;
+                    if (METRIC == VFSX_EUCLIDEAN) {
+                        const float diff = f_sub(qe[i], xv);
+                        pr = f_mul(diff, diff);
+                    } else {
+                        pr = f_mul(qe[i], xv);
+                    }
+                    dst[i] = in ? pr : 0.0f;
+                }
+                if (METRIC != VFSX_EUCLIDEAN && (lane >> 4) == 0u) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 16u; ++i)
+                        my_prod[4][my_c * EPC + i] = f_mul(qe[i], qe[i]);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const float xs[4] = {__uint_as_float(cur[j].x), __uint_as_float(cur[j].y), __uint_as_float(cur[j].z),
+                                         __uint_as_float(cur[j].w)};
+                    float4 pr;
+                    float *pp = &pr.x;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        if (METRIC == VFSX_EUCLIDEAN) {
+                            const float diff = f_sub(qe[i], xs[i]);
+                            pp[i] = f_mul(diff, diff);
+                        } else {
+                            pp[i] = f_mul(qe[i], xs[i]);
+                        }
+                        pp[i] = in ? pp[i] : 0.0f;
+                    }
+                    *(float4 *)&my_prod[j][my_c * EPC] = pr;
+                }
+                if (METRIC != VFSX_EUCLIDEAN)
+                    *(float4 *)&my_prod[4][my_c * EPC] =
+                        make_float4(f_mul(qe[0], qe[0]), f_mul(qe[1], qe[1]), f_mul(qe[2], qe[2]), f_mul(qe[3], qe[3]));
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations execute in program order
+            asm volatile("" ::: "memory");
+            // the fold: strictly in element order (rank.rs:281-300), one candidate per lane
+            if (lane < (METRIC == VFSX_EUCLIDEAN ? 4u : 5u)) {
+                const float *src = my_prod[lane];
+#pragma unroll 8
+                for (uint32_t e = 0; e < kCoopBlockElems; e += 4u) {
+                    const float4 t = *(const float4 *)(src + e);
+                    acc = f_add(acc, t.x);
+                    acc = f_add(acc, t.y);
+                    acc = f_add(acc, t.z);
+                    acc = f_add(acc, t.w);
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (uint32_t j = 0; j < NV; ++j)
+                cur[j] = nxt[j];
+        }
+        // lane j < 4: the exact distance of candidate g + j
+        if (METRIC != VFSX_EUCLIDEAN)
+            qn = f_sqrt(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 4))); // rank.rs:296
+        const uint32_t my_row = lane < 4u ? (lane == 0u ? r4[0] : (lane == 1u ? r4[1] : (lane == 2u ? r4[2] : r4[3]))) : 0u;
+        float dist;
+        if (METRIC == VFSX_EUCLIDEAN)
+            dist = f_sqrt(acc); // rank.rs:286
+        else
+            dist = f_sub(1.0f, f_div(acc, f_mul(qn, row_norms[my_row]))); // rank.rs:299
+        const uint64_t comp_g = ((uint64_t)dist_key(dist) << 32) | my_row;
+        // candidate g + j lives in lane g + j of the wave's offer vector
+        const uint32_t from = lane & 3u;
+        const uint64_t moved = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)(uint32_t)(comp_g >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)(uint32_t)comp_g);
+        if (lane >= g && lane < g + 4u)
+            mycomp = moved;
+    }
+    if (!in_range)
+        mycomp = kSentinel;
+
+    TopK top;
+    top.init(k, dyn_lds + wave * list_stride);
+    top.offer_dense(mycomp);
+    uint64_t *mine = dyn_lds + wave * list_stride;
+    __syncthreads();
+    top.spill(mine);
+    __syncthreads();
+    for (uint32_t s = 1; s < kCoopWaves; s <<= 1) { // merge tree over the waves' sorted lists
+        if ((wave & (2u * s - 1u)) == 0u) {
+            top.merge_list(dyn_lds + (wave + s) * list_stride);
+            top.spill(mine);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        for (uint32_t j = lane; j < k; j += 64) {
+            const uint64_t comp = mine[j];
+            vfsx_hit h;
+            if (comp == kSentinel) {
+                h.dist = __uint_as_float(0x7fc00000u);
+                h.flags = 0;
+                h.row = ~0ull;
+                h.id = ~0ull;
+            } else {
+                const uint32_t r = (uint32_t)comp;
+                h.dist = key_dist((uint32_t)(comp >> 32));
+                h.flags = 1;
+                h.row = row_base + r;
+                h.id = ids ? ids[r] : id_base + r;
+            }
+            out[(size_t)q * k + j] = h;
+        }
+        if (lane == 0) {
+            const uint64_t kth = mine[k - 1];
+            s_dk = kth == kSentinel ? __uint_as_float(0x7fc00000u) : key_dist((uint32_t)(kth >> 32));
+        }
+    }
+    if (threadIdx.x < 256u)
+        s_list[threadIdx.x] = 0xffffffffu - threadIdx.x;
+    __syncthreads();
+
+    // safety check: as in mfma_rescore_kernel, candidate ci in lane ci % cpw of wave ci / cpw
+    const float dk = s_dk;
+    bool bad = !(dk == dk) || !(dk < __uint_as_float(0x7f800000u));
+    bool above;
+    if (METRIC == VFSX_EUCLIDEAN) {
+        const double a = (double)q_norm[q], gm = (double)gamma;
+        const double vk_low = a * a * (1.0 - gm) - (double)dk * (double)dk * (1.0 + gm);
+        const double sc = (double)score;
+        above = valid && (sc + 0x1p-12 * (sc < 0.0 ? -sc : sc) >= vk_low);
+    } else {
+        const float thr = (1.0f - dk) - (q_eps[q] + 0x1p-13f);
+        above = valid && (q_scale ? q_scale[q] * score : score) >= thr;
+    }
+    if (lane < cpw && ci == kp - 1u && valid && above)
+        bad = true;
+    if (lane < cpw && above)
+        s_list[ci] = (uint32_t)comp_a;
+    __syncthreads();
+    if (lane < cpw && above) {
+        const uint32_t my = (uint32_t)comp_a;
+        uint32_t same = 0;
+        for (uint32_t j = 0; j < ci; ++j)
+            same += (s_list[j] == my) ? 1u : 0u;
+        if (same + 1u >= kListDepth)
+            bad = true;
+    }
+    if (lane < cpw && valid && !in_range)
+        bad = true;
+    if (bad)
+        atomicOr(&s_flag, 1);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        flags[q] = s_flag;
+}
+
 } // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------------
@@ -1575,17 +1833,26 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
                        a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks, a.q_stride,     \
                        a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma, a.only_flagged,   \
                        a.q_scale)
+    // batches of <= 256 queries: the cooperative kernel (16 waves per query, lanes share the rows)
+    const size_t lds_coop = (size_t)kCoopWaves * list_stride * sizeof(uint64_t);
+#define VFSX_RESCORE_C(DT, M, TOPK)                                                                                  \
+    hipLaunchKernelGGL((mfma_rescore_coop_kernel<DT, M, TOPK>), dim3(nq), dim3(64 * kCoopWaves), lds_coop, s,        \
+                       a.corpus, a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,      \
+                       a.d_chunks, a.q_stride, a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm,    \
+                       a.gamma, a.only_flagged, a.q_scale)
 #define VFSX_RESCORE(DT, M)                                                                                          \
     do {                                                                                                             \
-        if (a.k <= kMaxRegisterK && nq <= 256u)                                                                      \
-            VFSX_RESCORE_T(DT, M, WaveTopKReg, true);                                                                \
+        if (a.k <= kMaxRegisterK && coop)                                                                            \
+            VFSX_RESCORE_C(DT, M, WaveTopKReg);                                                                      \
         else if (a.k <= kMaxRegisterK)                                                                               \
             VFSX_RESCORE_T(DT, M, WaveTopKReg, false);                                                               \
-        else if (nq <= 256u)                                                                                         \
-            VFSX_RESCORE_T(DT, M, WaveTopKReg2, true);                                                               \
+        else if (coop)                                                                                               \
+            VFSX_RESCORE_C(DT, M, WaveTopKReg2);                                                                     \
         else                                                                                                         \
             VFSX_RESCORE_T(DT, M, WaveTopKReg2, false);                                                              \
     } while (0)
+    static const bool coop_on = !(std::getenv("VFSX_MFMA_COOP") && std::getenv("VFSX_MFMA_COOP")[0] == '0');
+    const bool coop = coop_on && nq <= 256u && (a.kp == 64u || a.kp == 128u || a.kp == 256u);
     if (dtype == VFSX_I8) {
         if (a.euclid)
             VFSX_RESCORE(VFSX_I8, VFSX_EUCLIDEAN);
@@ -1598,6 +1865,7 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
             VFSX_RESCORE(VFSX_F32, VFSX_COSINE);
     }
 #undef VFSX_RESCORE
+#undef VFSX_RESCORE_C
 #undef VFSX_RESCORE_T
     return hipGetLastError();
 }
