@@ -19,4 +19,11 @@ run c4i8 400 --workload c4i8 --no-cpu-baseline &&
 run c4auto 400 --workload c4auto --no-cpu-baseline &&
 run c4eauto 400 --workload c4eauto --no-cpu-baseline &&
 run c3b 400 --workload c3b --no-cpu-baseline &&
+run c3i 300 --workload c3i --steps 20 --warmup 5 --no-cpu-baseline &&
+run c2m 300 --workload c2m --no-cpu-baseline &&
+run c5m 300 --workload c5m --no-cpu-baseline &&
+run c2_k100 300 --workload c2 --k 100 --steps 10 --warmup 3 --no-cpu-baseline &&
+run c2_k1000 300 --workload c2 --k 1000 --steps 10 --warmup 3 --no-cpu-baseline &&
+run c1_k64 300 --workload c1 --k 64 --steps 10 --warmup 3 --no-cpu-baseline &&
+run c1_k100 300 --workload c1 --k 100 --steps 10 --warmup 3 --no-cpu-baseline &&
 VFSX_BENCH_BACKEND=gloo run g2_gloo 400 --gpus 2 --workload c2 --steps 5 --warmup 1
