@@ -174,9 +174,10 @@ def test_c2_single_queries_through_the_mirror_equal_exact_scan(oracle):
                 ids_m, dist_m, cnt_m = c.search_batch(queries[i:i + 1], k, metric)
                 assert (ids_m[0] == ids_e[i]).all() and (bits(dist_m[0]) == bits(dist_e[i])).all() and cnt_m[0] == k
             mq, fb = c.mfma_stats()
-            if k == 10:  # (k = 100 on random 768-d rows: hundreds of rows within the margin of the 100th, most
-                #          queries go back to the exact scan and the path backs off -- results are what counts there)
+            if k == 10:
                 assert mq == len(queries) and fb <= 2, (mirror, metric, k, mq, fb)
+            else:  # k > 32: single queries keep the exact scan (most would fail the check on such rows)
+                assert mq == 0
     c.close()
     small = vfs_amd.Corpus(128, capacity_rows=100_000)
     small.fill_synthetic(SEED_C, 100_000)

@@ -206,6 +206,8 @@ struct vfsx_corpus {
     // happening (1, 3, 7, ... 63 batches), and probe again afterwards
     uint32_t mfma_backoff = 0, mfma_backoff_next = 0;
     uint32_t mirror_win_queries = 0, mirror_win_flagged = 0; // auto mirror choice: queries / margin failures seen
+    uint32_t small_win_queries = 0, small_win_flagged = 0;   // calls of < 4 queries through the path: the same
+    uint32_t small_off = 0;                                  // ... and how many such queries still skip it
 
     // profiling
     bool profiling = false;
@@ -852,6 +854,15 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         uint32_t flagged = 0;
         for (uint32_t q = 0; q < nq; ++q)
             flagged += c->h_flags[q] ? 1u : 0u;
+        if (nq < 4u) { // see mfma_min_batch_for
+            c->small_win_queries += nq;
+            c->small_win_flagged += flagged;
+            if (c->small_win_queries >= 64u) {
+                if (c->small_win_flagged * 4u > c->small_win_queries)
+                    c->small_off = 8192u;
+                c->small_win_queries = c->small_win_flagged = 0;
+            }
+        }
         bool to_bf16 = false;
         if (mirror_is_i8(c) && c->mirror_pref == 0) {
             // auto: does the int8 mirror's wider margin send too many of this data's queries back?  (Queries the
@@ -933,11 +944,14 @@ void chain_search_stream(vfsx_corpus *c, hipStream_t s)
 // path's fixed ~120 us (launch chain, re-score gather, flag read-back) even a single query is faster through it
 // (1M x 768: 0.243 vs 0.449 ms; 12.5M x 768: 1.56 vs 5.48 ms) -- from 4e8 elements on with the int8 mirror, 6e8 with
 // the bf16 one.  VFSX_MFMA_MIN_BATCH overrides.
-uint32_t mfma_min_batch_for(const vfsx_corpus *c)
+// Only for k <= 32 (at k = 100 on random 768-d rows most single queries fail the check: 1M x 768 2150 q/s exact,
+// 870 through the path), and only while such calls mostly pass: a window of 64 of them with more than a quarter
+// flagged keeps the next 8192 on the exact scan (then the path is probed again).
+uint32_t mfma_min_batch_for(const vfsx_corpus *c, uint32_t k)
 {
     if (c->mfma_min_batch)
         return c->mfma_min_batch;
-    if (c->dtype == VFSX_F32) {
+    if (c->dtype == VFSX_F32 && k <= 32u && c->small_off == 0u) {
         const uint64_t elems = c->n_rows * (uint64_t)c->dim;
         if (elems >= (mirror_is_i8(c) ? 400000000ull : 600000000ull))
             return 1;
@@ -957,9 +971,11 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     if (!d_queries || !d_hits)
         fail(VFSX_ERR_INVALID_VECTOR, "null query/output buffer");
     chain_search_stream(c, s);
+    if (nq < 4u && c->small_off > 0u)
+        c->small_off -= std::min(c->small_off, nq);
     // the reference's four metrics; the integer-domain extension has its own kernel
     const bool metric_ok = metric != VFSX_EUCLIDEAN_I8DOMAIN;
-    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= mfma_min_batch_for(c) && k <= vfsx::kMfmaMaxK && c->dim <= vfsx::kMfmaMaxDim &&
+    const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= mfma_min_batch_for(c, k) && k <= vfsx::kMfmaMaxK && c->dim <= vfsx::kMfmaMaxDim &&
                          c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok && c->mfma_backoff > 0) {
         --c->mfma_backoff; // see vfsx_corpus::mfma_backoff
@@ -1362,6 +1378,7 @@ int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
         c->mfma_enabled = enable != 0;
         c->mfma_backoff = c->mfma_backoff_next = 0;
         c->mirror_win_queries = c->mirror_win_flagged = 0;
+        c->small_win_queries = c->small_win_flagged = c->small_off = 0;
         if (!enable) {
             free_mirror(c);
             return;
