@@ -514,3 +514,36 @@ def test_mfma_result_limits_up_to_128(oracle, quantize, k, mirror_kind):
     c.search_batch(queries, 129, 1)
     assert c.mfma_stats()[0] == 0
     c.close()
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_mfma_appends_extend_the_operand(oracle, quantize):
+    """Rows appended after the batch path was built: an int8 operand (mirror of an f32 store, or an int8 store's row
+    factors) only adds the new rows' part -- within the reserved capacity and across a capacity growth -- and the
+    largest residual carries over; a bf16 mirror is rebuilt.  After every append the batch equals the exact scan of a
+    twin corpus that never had the path on, Cosine and Euclidean, and the near-duplicate of a query appended just
+    now is found."""
+    import vfs_amd
+    rng = np.random.default_rng(77)
+    d = 96
+    c = vfs_amd.Corpus(d, quantize=quantize, capacity_rows=60000)
+    twin = vfs_amd.Corpus(d, quantize=quantize, capacity_rows=60000)
+    c.enable_mfma(True)
+    queries = rng.uniform(-1, 1, (12, d)).astype(np.float32)
+    total = 0
+    for step, n_new in enumerate((30000, 1, 63, 4000, 257, 40000)):  # the last one outgrows the capacity
+        rows = rng.uniform(-1, 1, (n_new, d)).astype(np.float32)
+        rows[0] = queries[step % len(queries)] * 0.5 + rng.uniform(-1e-3, 1e-3, d).astype(np.float32)
+        for x in (c, twin):
+            (x.append_f32 if quantize else x.append)(rows)
+        total += n_new
+        for metric in (1, 0):
+            c.mfma_stats(reset=True)
+            im, dm, cm = c.search_batch(queries, 10, metric)
+            assert c.mfma_stats()[0] == len(queries)
+            ie, de, ce = twin.search_batch(queries, 10, metric)
+            assert (im == ie).all() and (bits(dm) == bits(de)).all() and (cm == ce).all()
+            if metric == 1:
+                assert im[step % len(queries), 0] == total - n_new + 1  # (ids start at 1): the row appended just now
+    c.close()
+    twin.close()

@@ -693,8 +693,16 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
         const bool i8 = prefilter_is_i8(c);
         const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
         const size_t n_pad = (size_t)g.n_rowtiles * 256u;
+        // int8 operands are sized for the corpus' CAPACITY, so that appended rows only add their own part below
+        const vfsx::MfmaGeometry gc = vfsx::mfma_geometry((uint32_t)std::max<uint64_t>(c->capacity, c->n_rows), c->dim, i8);
+        const size_t cap_pad = i8 ? (size_t)gc.n_rowtiles * 256u : n_pad;
         const size_t want = c->dtype == VFSX_I8 ? 0
-                            : (mirror_is_i8(c) ? (n_pad / 64u) * mirror_i8_chunks(c) * 1024u : g.mirror_bytes);
+                            : (mirror_is_i8(c) ? (cap_pad / 64u) * mirror_i8_chunks(c) * 1024u : g.mirror_bytes);
+        // appended rows on an int8 operand that was complete and good before: only rows [mirror_rows, n_rows)
+        uint32_t row0 = 0;
+        if (i8 && c->d_rn2 && c->mirror_rows > 0 && c->mirror_rows < c->n_rows && !c->mirror_bad &&
+            want <= c->mirror_bytes && n_pad <= c->rn2_rows)
+            row0 = (uint32_t)c->mirror_rows;
         if (want > c->mirror_bytes) {
             free_mirror(c);
             HIP_CHECK(hipMalloc((void **)&c->d_mirror, want));
@@ -702,8 +710,12 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
         }
         if (!c->d_mirror_stats)
             HIP_CHECK(hipMalloc((void **)&c->d_mirror_stats, 2 * sizeof(uint32_t)));
-        HIP_CHECK(hipMemsetAsync(c->d_mirror_stats, 0, 2 * sizeof(uint32_t), s));
-        if (n_pad > c->rn2_rows) { // Euclidean batches: (b, b^2 (1 - gamma)) per row; int8 operands: the row factor
+        uint32_t st0[2] = {0, 0};
+        if (row0)
+            std::memcpy(&st0[1], &c->mirror_rx, sizeof(float)); // the maximum residual carries over
+        HIP_CHECK(hipMemcpyAsync(c->d_mirror_stats, st0, sizeof(st0), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s)); // (st0 lives on this stack frame)
+        if (cap_pad > c->rn2_rows) { // Euclidean batches: (b, b^2 (1 - gamma)) per row; int8 operands: the row factor
             if (c->d_rn2)
                 (void)hipFree(c->d_rn2);
             if (c->d_inv_rn)
@@ -711,22 +723,25 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
             c->d_rn2 = nullptr;
             c->d_inv_rn = nullptr;
             c->rn2_rows = 0;
-            HIP_CHECK(hipMalloc((void **)&c->d_rn2, n_pad * 2u * sizeof(float)));
-            HIP_CHECK(hipMalloc((void **)&c->d_inv_rn, n_pad * sizeof(float)));
-            c->rn2_rows = n_pad;
+            HIP_CHECK(hipMalloc((void **)&c->d_rn2, cap_pad * 2u * sizeof(float)));
+            HIP_CHECK(hipMalloc((void **)&c->d_inv_rn, cap_pad * sizeof(float)));
+            c->rn2_rows = cap_pad;
+            row0 = 0;
         }
         if (mirror_is_i8(c)) {
-            HIP_CHECK(hipMemsetAsync(c->d_mirror, 0, want, s)); // rows beyond n_rows are read (and masked)
-            HIP_CHECK(hipMemsetAsync(c->d_inv_rn, 0, n_pad * sizeof(float), s));
+            if (!row0) {
+                HIP_CHECK(hipMemsetAsync(c->d_mirror, 0, want, s)); // rows beyond n_rows are read (and masked)
+                HIP_CHECK(hipMemsetAsync(c->d_inv_rn, 0, c->rn2_rows * sizeof(float), s));
+            }
             HIP_CHECK(vfsx::launch_mfma_mirror_i8(c->d_corpus, c->d_norms, c->d_mirror, c->d_inv_rn, (uint32_t)c->n_rows,
-                                                  c->d_chunks, mirror_i8_chunks(c), g.k_pad, c->d_mirror_stats, s));
+                                                  c->d_chunks, mirror_i8_chunks(c), g.k_pad, c->d_mirror_stats, s, row0));
         } else if (c->dtype == VFSX_F32) {
             HIP_CHECK(vfsx::launch_mfma_mirror(c->dtype, c->d_corpus, c->d_norms, c->d_lut, c->d_mirror,
                                                (uint32_t)c->n_rows, c->dim, c->d_chunks, g, c->d_mirror_stats, s));
         }
         HIP_CHECK(vfsx::launch_mfma_rownorm_pairs(c->d_norms, (uint32_t)c->n_rows, (uint32_t)n_pad, mfma_gamma(g.k_pad),
                                                   c->d_rn2, c->dtype == VFSX_I8 ? c->d_inv_rn : nullptr, c->scale,
-                                                  c->d_mirror_stats, s));
+                                                  c->d_mirror_stats, s, row0));
         uint32_t st[2] = {0, 0};
         HIP_CHECK(hipMemcpyAsync(st, c->d_mirror_stats, sizeof(st), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));

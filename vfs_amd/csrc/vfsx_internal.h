@@ -153,7 +153,7 @@ hipError_t launch_mfma_query_prep(const float *d_queries, uint32_t nq, uint32_t 
 // out[n_pad] float2 = (b, b^2 (1 - gamma)), zero beyond n_rows; inv[n_pad] (or nullptr) = 1 / (i8_scale b); stats[0]
 // is raised for a norm outside the path's range
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
-                                     float *inv, float i8_scale, uint32_t *stats, hipStream_t s);
+                                     float *inv, float i8_scale, uint32_t *stats, hipStream_t s, uint32_t row0 = 0);
 // int8 stores: no mirror -- the prefilter reads the rb64 corpus; the queries are quantized per batch
 // stats: nullptr for an int8 store (exact rows), the mirror's stats for an int8 mirror of an f32 store (R_x)
 hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32_t dim, void *q_mirror, uint32_t KS,
@@ -163,7 +163,7 @@ hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32
 // whole 64-row blocks and be zeroed beforehand), inv_rn[row] = the row's scale, stats[0] / stats[1] as launch_mfma_mirror
 hipError_t launch_mfma_mirror_i8(const uint4 *corpus, const float *row_norms, uint4 *mirror, float *inv_rn,
                                  uint32_t n_rows, uint32_t d_chunks, uint32_t d_chunks8, uint32_t k_pad,
-                                 uint32_t *stats, hipStream_t s);
+                                 uint32_t *stats, hipStream_t s, uint32_t row0 = 0); // rows [row0, n_rows)
 hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint64_t corpus_bytes, const void *q_mirror,
                                     float *cand, uint32_t n_rows, const MfmaGeometry &g, uint32_t nq, int euclid,
                                     const float *rn2, const float *inv_rn, const float *q_norm, const float *q_eps,

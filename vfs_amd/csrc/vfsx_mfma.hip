@@ -166,9 +166,10 @@ __global__ void mfma_residual_kernel(const uint4 *__restrict__ corpus, const flo
 // One thread per row (lane l of a wave = row 64 b + l: every load and store is a coalesced 1 KiB).
 __global__ void mfma_mirror_i8_kernel(const uint4 *__restrict__ corpus, const float *__restrict__ row_norms,
                                       uint4 *__restrict__ mirror, float *__restrict__ inv_rn, uint32_t n_rows,
-                                      uint32_t d_chunks, uint32_t d_chunks8, uint32_t K, uint32_t *__restrict__ stats)
+                                      uint32_t d_chunks, uint32_t d_chunks8, uint32_t K, uint32_t *__restrict__ stats,
+                                      uint32_t row0)
 {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t row = row0 + blockIdx.x * blockDim.x + threadIdx.x; // rows [row0, n_rows): an append only adds these
     float r = 0.0f;
     if (row < n_rows) {
         const float b = row_norms[row];
@@ -224,9 +225,9 @@ __global__ void mfma_mirror_i8_kernel(const uint4 *__restrict__ corpus, const fl
 // for a norm outside the path's range (the bf16 mirror kernel does the same).
 __global__ void mfma_rownorm_pairs_kernel(const float *__restrict__ row_norms, uint32_t n_rows, uint32_t n_pad,
                                           float gamma, float2 *__restrict__ out, float *__restrict__ inv,
-                                          float i8_scale, uint32_t *__restrict__ stats)
+                                          float i8_scale, uint32_t *__restrict__ stats, uint32_t row0)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = row0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_pad)
         return;
     float b = 0.0f, bsq = 0.0f, iv = 0.0f;
@@ -1642,10 +1643,12 @@ namespace vfsx {
 #endif
 
 hipError_t launch_mfma_rownorm_pairs(const float *row_norms, uint32_t n_rows, uint32_t n_pad, float gamma, float *out,
-                                     float *inv, float i8_scale, uint32_t *stats, hipStream_t s)
+                                     float *inv, float i8_scale, uint32_t *stats, hipStream_t s, uint32_t row0)
 {
-    hipLaunchKernelGGL(mfma_rownorm_pairs_kernel, dim3((n_pad + 255u) / 256u), dim3(256), 0, s, row_norms, n_rows,
-                       n_pad, gamma, (float2 *)out, inv, i8_scale, stats);
+    if (row0 >= n_pad)
+        return hipSuccess;
+    hipLaunchKernelGGL(mfma_rownorm_pairs_kernel, dim3((n_pad - row0 + 255u) / 256u), dim3(256), 0, s, row_norms, n_rows,
+                       n_pad, gamma, (float2 *)out, inv, i8_scale, stats, row0);
     return hipGetLastError();
 }
 
@@ -1660,10 +1663,12 @@ hipError_t launch_mfma_query_prep_i8(const float *d_queries, uint32_t nq, uint32
 
 hipError_t launch_mfma_mirror_i8(const uint4 *corpus, const float *row_norms, uint4 *mirror, float *inv_rn,
                                  uint32_t n_rows, uint32_t d_chunks, uint32_t d_chunks8, uint32_t k_pad,
-                                 uint32_t *stats, hipStream_t s)
+                                 uint32_t *stats, hipStream_t s, uint32_t row0)
 {
-    hipLaunchKernelGGL(mfma_mirror_i8_kernel, dim3((n_rows + 255u) / 256u), dim3(256), 0, s, corpus, row_norms, mirror,
-                       inv_rn, n_rows, d_chunks, d_chunks8, k_pad, stats);
+    if (row0 >= n_rows)
+        return hipSuccess;
+    hipLaunchKernelGGL(mfma_mirror_i8_kernel, dim3((n_rows - row0 + 255u) / 256u), dim3(256), 0, s, corpus, row_norms,
+                       mirror, inv_rn, n_rows, d_chunks, d_chunks8, k_pad, stats, row0);
     return hipGetLastError();
 }
 
