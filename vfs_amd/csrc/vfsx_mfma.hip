@@ -1155,7 +1155,7 @@ __device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32
     return (strip * strip_tiles + ts) * 256u + wave_m * 128u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
 }
 
-template <int DTYPE, int METRIC, typename TopK, bool DEEP>
+template <int DTYPE, int METRIC, typename TopK>
 __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const uint4 *__restrict__ corpus, const float *__restrict__ row_norms, const float *__restrict__ queries,
     const float *__restrict__ lut, const uint64_t *__restrict__ sel, const int *__restrict__ q_bad,
@@ -1202,23 +1202,9 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
         const uint32_t r = in_range ? row : 0u;
         const uint4 *__restrict__ p = corpus + (size_t)(r >> 6) * d_chunks * 64u + (r & 63u);
         Acc acc[1] = {Acc{0.0f, 0.0f}};
-        // a gather: 16 B per 1 KiB of the row's block, latency-bound -> 8 loads in flight per lane; DEEP (small
-        // batches: a handful of waves on the whole chip, each with its SIMD to itself) 32 first -- 1M x 768 f32,
-        // 64 queries: 100 -> 76 us; on 4096-query batches the 128 extra VGPRs cost occupancy (+0.8 ms per batch)
+        // a gather: 16 B per 1 KiB of the row's block, latency-bound -> 8 loads in flight per lane (batches of
+        // <= 256 queries take mfma_rescore_coop_kernel below; here thousands of workgroups keep the memory busy)
         uint32_t c = 0;
-        for (; DEEP && c + 32u <= d_chunks; c += 32u) {
-            uint4 v[32];
-#pragma unroll
-            for (uint32_t u = 0; u < 32u; ++u)
-                v[u] = p[(size_t)(c + u) * 64u];
-#pragma unroll
-            for (uint32_t u = 0; u < 32u; ++u) {
-                if (DTYPE == VFSX_I8)
-                    acc_chunk_i8<METRIC, true, 1>(acc, v[u], qv + (c + u) * EPC, 0, lut_lane);
-                else
-                    acc_chunk_f32<METRIC, true, 1>(acc, v[u], qv + (c + u) * EPC, 0);
-            }
-        }
         for (; c + 8u <= d_chunks; c += 8u) {
             uint4 v[8];
 #pragma unroll
@@ -1832,8 +1818,8 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     const uint32_t list_stride = a.k > 64u ? 128u : 64u;
     const size_t lds = (size_t)kWavesPerBlock * list_stride * sizeof(uint64_t);
     // k <= 64: one register per lane; k <= 128 (kMfmaMaxK): two
-#define VFSX_RESCORE_T(DT, M, TOPK, DEEP)                                                                                \
-    hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, TOPK, DEEP>), dim3(nq), dim3(kBlock), lds, s, a.corpus,            \
+#define VFSX_RESCORE_T(DT, M, TOPK)                                                                                      \
+    hipLaunchKernelGGL((mfma_rescore_kernel<DT, M, TOPK>), dim3(nq), dim3(kBlock), lds, s, a.corpus,                  \
                        a.row_norms,                                                                                  \
                        a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks, a.q_stride,     \
                        a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma, a.only_flagged,   \
@@ -1850,11 +1836,11 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
         if (a.k <= kMaxRegisterK && coop)                                                                            \
             VFSX_RESCORE_C(DT, M, WaveTopKReg);                                                                      \
         else if (a.k <= kMaxRegisterK)                                                                               \
-            VFSX_RESCORE_T(DT, M, WaveTopKReg, false);                                                               \
+            VFSX_RESCORE_T(DT, M, WaveTopKReg);                                                                      \
         else if (coop)                                                                                               \
             VFSX_RESCORE_C(DT, M, WaveTopKReg2);                                                                     \
         else                                                                                                         \
-            VFSX_RESCORE_T(DT, M, WaveTopKReg2, false);                                                              \
+            VFSX_RESCORE_T(DT, M, WaveTopKReg2);                                                                     \
     } while (0)
     static const bool coop_on = !(std::getenv("VFSX_MFMA_COOP") && std::getenv("VFSX_MFMA_COOP")[0] == '0');
     const bool coop = coop_on && nq <= 256u && (a.kp == 64u || a.kp == 128u || a.kp == 256u);
