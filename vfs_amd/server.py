@@ -112,17 +112,27 @@ def err_body(msg: str) -> str:
 
 # ---- the state behind the mutex (ServerState, tcp.rs:60-63) --------------------------------------
 
+
+def _new_corpus(dim: int, quantize: bool, device: int):
+    """The resident store.  VFSX_SERVER_MIRROR=1 switches the matrix-core path on (no reference counterpart; results
+    unchanged): /search on an f32 store of >= 4e8 elements with ef_search <= 32 is then pre-filtered from the 1 B per
+    element int8 mirror instead of scanning 4 B per element; inserts extend the mirror (vfsx_api.cpp ensure_mirror)."""
+    import vfs_amd
+    corpus = vfs_amd.Corpus(dim, quantize=quantize, device=device)
+    if os.environ.get("VFSX_SERVER_MIRROR", "0") not in ("", "0"):
+        corpus.enable_mfma(True)
+    return corpus
+
 FLUSH_THRESHOLD = 10  # storage_manager.rs:12
 
 
 class ServerState:
     def __init__(self, dim: int, quantize: bool, name: str, device: int = 0, state_dir: str = "state",
                  data_dir: str = "data"):
-        import vfs_amd
         self.vector_dimension = dim
         self.quantize = quantize
         self.name = name
-        self.corpus = vfs_amd.Corpus(dim, quantize=quantize, device=device)
+        self.corpus = _new_corpus(dim, quantize, device)
         self.next_id = 1                      # storage_manager.rs:76
         self.row_of = {}                      # id -> local row
         self.meta = {}                        # id -> (name, tags) as the store holds them
@@ -393,10 +403,9 @@ class App:
             return 500, err_body("Failed to load state: Internal error: snapshot storage type differs from the "
                                  "resident corpus")
         if saved["quantize"] != st.quantize:  # empty store: adopt the snapshot's storage type
-            import vfs_amd
             st.corpus.close()
             st.quantize = saved["quantize"]
-            st.corpus = vfs_amd.Corpus(st.vector_dimension, quantize=st.quantize, device=self.device)
+            st.corpus = _new_corpus(st.vector_dimension, st.quantize, self.device)
         st.name = saved["name"]
         st.index_map = dict(saved["index_map"])
         st.current_offset = saved["current_offset"]
