@@ -21,6 +21,7 @@ Inputs are resident in HBM before the timed region (synthetic, generated on devi
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import socket
@@ -156,21 +157,35 @@ def main(argv=None) -> int:
     backend = os.environ.get("VFSX_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo for rehearsals
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
+    # every wait on a peer is bounded: a rank that never arrives fails the job instead of hanging it
+    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("VFSX_BENCH_PG_TIMEOUT_S", "600")))
+    fault = os.environ.get("VFSX_BENCH_FAULT", "")  # rehearsals: "exit_before_agree:<rank>"
+
     if args.dry_run:
-        joined = 1
+        joined, preflight = 1, None
         if world > 1:
             use_nccl = backend == "nccl" and torch.cuda.is_available()
-            dist.init_process_group("nccl" if use_nccl else "gloo")
+            dist.init_process_group("nccl" if use_nccl else "gloo", timeout=pg_timeout)
+            if fault == f"exit_before_agree:{rank}":
+                os._exit(7)  # a rank that dies before the communicator is agreed on
             t = torch.ones(1, dtype=torch.int64)
             if use_nccl:
                 t = t.cuda(local_rank % torch.cuda.device_count())
             dist.all_reduce(t)
             joined = int(t.item())
+            # the agreement that precedes vfsx_comm_init in a real run (pre-flight of every rank + rank 0's id); no
+            # rank enters ncclCommInitRank here.  Without GPUs every rank reports "device not visible".
+            from vfs_amd import sharded
+            try:
+                sharded.Comm.agree(local_rank)
+                preflight = "ok"
+            except RuntimeError as e:
+                preflight = str(e)
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"dry_run": True, "ranks_joined": joined, "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "config": config}), flush=True)
+                              "warmup": args.warmup, "comm_preflight": preflight, "config": config}), flush=True)
         return 0
 
     if not torch.cuda.is_available():
@@ -186,19 +201,34 @@ def main(argv=None) -> int:
     comm = None
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-            try:  # the library's own RCCL communicator (vfsx_comm_*)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
+            if fault == f"exit_before_agree:{rank}":
+                os._exit(7)
+            # first contact: one tiny all-reduce on torch's communicator (a rank that cannot reach its peers fails
+            # HERE, within pg_timeout), then the library's own RCCL communicator (vfsx_comm_*).  Comm.bootstrap
+            # agrees over the group that every rank passed its pre-flight BEFORE anyone enters ncclCommInitRank,
+            # so its exception is raised on all ranks or on none; vfsx_comm_init bounds the rest by its watchdog.
+            t = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(t)
+            if int(t.item()) != world:
+                print(f"[bench rank {rank}] first all-reduce returned {int(t.item())}, expected {world}", file=sys.stderr)
+                return 3
+            try:
                 comm = sharded.Comm.bootstrap(local_rank)
+                comm.reserve(qps_step * k)  # the exchange never allocates inside the timed region
             except Exception as e:  # noqa: BLE001
                 print(f"[bench rank {rank}] vfsx_comm bootstrap failed ({e}); torch.distributed all-gather instead",
                       file=sys.stderr, flush=True)
+                comm = None
             ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm = None
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
+            if fault == f"exit_before_agree:{rank}":
+                os._exit(7)
 
     debug = bool(os.environ.get("VFSX_BENCH_DEBUG"))
 
@@ -462,6 +492,19 @@ def main(argv=None) -> int:
             out["with_int8_mirror"] = {"error": f"{type(e).__name__}: {e}"}
         corpus.enable_mfma(False)
 
+    # Side leg (not `value`): what ONE GPU does on the shard the N > 1 runs give every rank (12.5M x 768 f32 Euclidean,
+    # 38.4 GB).  The driver's N = 1 line is C2 and its N > 1 lines are C5 shards, so this is the number the N > 1
+    # `value`s are to be read against: ideal weak scaling is a constant `value` equal to it.
+    if (world == 1 and workload == "c2" and not args.rows and not args.dim and args.metric < 0
+            and not os.environ.get("VFSX_BENCH_NO_C5_LEG")):
+        try:
+            out["c5_shard_one_gpu"] = c5_shard_leg(vfs_amd, synth, torch, dev, local_rank, k)
+        except Exception as e:  # noqa: BLE001 -- a side leg must not cost the line
+            out["c5_shard_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+        out["scaling_note"] = ("this N = 1 line is BASELINE config 2 (1M rows); `--gpus N` lines (N > 1) are weak scaling "
+                               "on BASELINE config 5's shard, 12.5M x 768 f32 Euclidean per GPU: their ideal `value` is "
+                               "c5_shard_one_gpu.value (the corpus grows with N, the query rate stays), NOT this line's value")
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, rows, dim, quantize, metric, k)
     if rank == 0:
@@ -474,6 +517,66 @@ def main(argv=None) -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def c5_shard_leg(vfs_amd, synth, torch, dev, device_index, k):
+    """One C5 shard (WORKLOADS["c5"]) on this GPU: 4 untimed + 128 timed single-query Euclidean scans, wall-clocked
+    like the main region, plus the scan kernel's average from HIP events on its stream."""
+    rows, dim, _, metric, _, label = WORKLOADS["c5"]
+    n_q, n_warm = 128, 4
+    shard = vfs_amd.Corpus(dim, capacity_rows=rows, device=device_index)
+    try:
+        shard.fill_synthetic(synth.CORPUS_SEED, rows, row0=0, id0=1)
+        d_q = torch.from_numpy(synth.rows_f32(synth.QUERY_SEED, 0, n_q + n_warm, dim)).to(dev)
+        d_hits = torch.zeros((n_q + n_warm, k, 6), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def scans(lo, hi):
+            for j in range(lo, hi):
+                shard.search_device(d_q[j].data_ptr(), 1, k, metric, d_hits[j].data_ptr(), stream)
+            torch.cuda.synchronize()
+
+        scans(0, n_warm)
+        t0 = time.perf_counter()
+        scans(n_warm, n_warm + n_q)
+        dt = time.perf_counter() - t0
+        shard.set_profiling(True)
+        scans(n_warm, n_warm + 16)
+        ms, launches = shard.scan_time_ms()
+        shard.set_profiling(False)
+        avg_ms = ms / max(launches, 1)
+        gbps = rows * dim * 4 / (avg_ms * 1e-3) / 1e9
+        return {"value": round(n_q / dt, 3), "unit": "queries/s", "queries": n_q, "avg_kernel_ms": round(avg_ms, 5),
+                "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "workload": label,
+                "what": "measured in this run after the timed region: one 12.5M x 768 f32 shard, one scan launch per "
+                        "query; the ideal `value` of every `--gpus N` line (N x this many shard scans per second)"}
+    finally:
+        shard.close()
+
+
+def rust_nightly_leg():
+    """SURVEY 8(d) / BASELINE.md: the reference's own nightly core::simd path can only be timed where a Rust
+    nightly toolchain exists.  Probe it; say so when it does not."""
+    try:
+        r = subprocess.run(["cargo", "+nightly", "--version"], capture_output=True, text=True, timeout=20)
+    except FileNotFoundError:
+        return "unavailable (no cargo on this box: the reference's nightly core::simd path cannot be built here)"
+    except (OSError, subprocess.SubprocessError) as e:
+        return f"unavailable (cargo +nightly --version: {type(e).__name__})"
+    if r.returncode != 0:
+        return "unavailable (cargo present, no nightly toolchain: " + (r.stderr.strip().splitlines() or ["?"])[-1][:120] + ")"
+    crate = os.path.join(ROOT, "rust", "simd_baseline")
+    try:
+        b = subprocess.run(["cargo", "+nightly", "run", "--release", "--offline", "--quiet"], cwd=crate,
+                           capture_output=True, text=True, timeout=300)
+    except (OSError, subprocess.SubprocessError) as e:
+        return f"unavailable (rust/simd_baseline did not run: {type(e).__name__})"
+    if b.returncode != 0:
+        return "unavailable (rust/simd_baseline did not build: " + (b.stderr.strip().splitlines() or ["?"])[-1][:160] + ")"
+    try:
+        return json.loads(b.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return "unavailable (rust/simd_baseline printed no JSON line)"
 
 
 def pmc_traffic(workload, rows):
@@ -520,6 +623,7 @@ def cpu_baseline(args, rows, dim, quantize, metric, k):
            "sample": f"{done} queries x first {n} rows of the same synthetic corpus "
                      f"({dt:.1f} s of CPU), rows/s scaled to the full {rows}-row corpus",
            "rows_per_s": round(rows_per_s, 1)}
+    out["rust_nightly"] = rust_nightly_leg()
     if metric in (2, 3) and dim not in (2, 4, 8, 16, 32, 64):
         out["note"] = ("the reference's Simd* methods panic unless d is one of 2..64 (rank.rs:31,303,307); this is the "
                        "scalar-order port, which Simd* equals bit for bit wherever it runs (ordered reduce_sum)")

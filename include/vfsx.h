@@ -95,7 +95,9 @@ int vfsx_device_count(void);
 
 /* Start-up check for a host that wants `n_devices` GPUs (one process per GPU passes 1): VFSX_OK when at
  * least that many gfx950 devices are visible, VFSX_ERR_NO_DEVICE otherwise -- the place to fail
- * loudly at boot (main.rs:47-62 has no counterpart: the reference needs no device).  Allocates nothing. */
+ * loudly at boot (main.rs:47-62 has no counterpart: the reference needs no device).  Allocates nothing; it
+ * touches devices 0 .. n_devices-1 once (context + the static workspace of vfsx_search_device_noalloc) and
+ * leaves the caller's current device as it found it. */
 int vfsx_init(int n_devices);
 
 /* Message of the last failure on this thread ("" if none). */
@@ -266,6 +268,10 @@ int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint
  * streams without ordering, or different host threads) race on it.  Nothing in the array needs to start at
  * zero: each launch overwrites what its select kernel reads.  Profiling (vfsx_corpus_set_profiling) does
  * not time these calls.
+ * Under HIP graph capture the launches bake in the corpus' device addresses and row count: a captured graph
+ * is valid until the next vfsx_corpus_append* / vfsx_corpus_load_log* / vfsx_corpus_enable_mfma on that corpus
+ * (a replay afterwards scans the old row count) -- capture again after such a call.  Storage is segmented
+ * ("HBM layout"): rows already stored never move when the corpus grows.
  */
 int vfsx_search_device_noalloc(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k,
                                int metric, vfsx_hit *d_hits, void *stream);
@@ -300,8 +306,18 @@ int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint
 typedef struct vfsx_comm vfsx_comm;
 
 int vfsx_comm_unique_id(void *id_out /* VFSX_COMM_ID_BYTES */);
-/* `device`: the HIP device this rank's corpus lives on.  NULL on failure (vfsx_last_error). */
+/* `device`: the HIP device this rank's corpus lives on.  NULL on failure (vfsx_last_error).
+ * The wait is bounded: ncclCommInitRank cannot be cancelled, so a rank still inside it after
+ * VFSX_COMM_INIT_TIMEOUT_S seconds (default 300; 0 = wait for ever) reports the peer that never joined on stderr and
+ * ends the PROCESS with status 3 -- agree among the ranks that every one is healthy BEFORE calling this (bench.py
+ * and vfs_amd.sharded do).  On success every buffer the exchange needs is allocated here, sized for
+ * VFSX_COMM_HITS hits per rank and batch (default 4096 x 10) and VFSX_COMM_QUERY_FLOATS query floats of the host
+ * entry point (default 4096 x 1024): searches within those sizes make no allocation in this layer afterwards. */
 vfsx_comm *vfsx_comm_init(int rank, int world, const void *id, int device);
+/* Widens those buffers (nq * k hits per rank and batch; query floats of vfsx_search_sharded_host, 0 = keep). */
+int vfsx_comm_reserve(vfsx_comm *comm, uint64_t hits_per_rank, uint64_t query_floats);
+/* Device / pinned allocations this communicator has made so far (tests: it must not move after init). */
+uint64_t vfsx_comm_alloc_count(const vfsx_comm *comm);
 void vfsx_comm_destroy(vfsx_comm *comm);
 int vfsx_comm_rank(const vfsx_comm *comm);
 int vfsx_comm_world(const vfsx_comm *comm);
@@ -312,7 +328,12 @@ int vfsx_comm_rccl_version(void);
  * The collective search: vfsx_search_device on this rank's shard, the all-gather, the merge -- all enqueued
  * on `stream` (the matrix-core batch path, if enabled on the corpus, synchronises it once as documented
  * below).  Every rank must call it with the same nq / k; d_hits[nq*k] receives the same global ranking on
- * every rank.
+ * every rank.  It is a collective: a rank that does not call it leaves the others waiting in the all-gather.  A
+ * rank whose LOCAL scan fails (bad arguments on that rank only, device memory that ran dry) still joins the
+ * all-gather, with an empty list, and then returns its error -- the peers complete with the remaining shards' hits
+ * and must learn of the failure from the host protocol.  Argument errors that every rank shares (k = 0, null
+ * handles) return before the collective on every rank alike.  Within the sizes reserved at vfsx_comm_init /
+ * vfsx_comm_reserve this layer allocates nothing; the corpus' own scan workspaces grow on its first searches.
  */
 int vfsx_search_sharded(vfsx_corpus *c, vfsx_comm *comm, const float *d_queries, uint32_t nq, uint32_t k,
                         int metric, vfsx_hit *d_hits, void *stream);

@@ -80,6 +80,8 @@ extern "C" {
     pub fn vfsx_comm_rank(comm: *const VfsxComm) -> c_int;
     pub fn vfsx_comm_world(comm: *const VfsxComm) -> c_int;
     pub fn vfsx_comm_rccl_version() -> c_int;
+    pub fn vfsx_comm_reserve(comm: *mut VfsxComm, hits_per_rank: u64, query_floats: u64) -> c_int;
+    pub fn vfsx_comm_alloc_count(comm: *const VfsxComm) -> u64;
     pub fn vfsx_search_sharded(c: *mut VfsxCorpus, comm: *mut VfsxComm, d_queries: *const f32, nq: u32, k: u32, metric: c_int, d_hits: *mut VfsxHit, stream: *mut c_void) -> c_int;
     pub fn vfsx_search_sharded_host(c: *mut VfsxCorpus, comm: *mut VfsxComm, queries: *const f32, nq: u32, k: u32, metric: c_int, out_ids: *mut u64, out_dist: *mut f32, out_count: *mut u32) -> c_int;
     pub fn vfsx_comm_merge_hits(comm: *mut VfsxComm, d_local: *const VfsxHit, nq: u32, k: u32, d_hits: *mut VfsxHit, stream: *mut c_void) -> c_int;
@@ -407,6 +409,15 @@ impl Comm {
     pub fn world(&self) -> i32 {
         unsafe { vfsx_comm_world(self.h) }
     }
+    /// Widens the exchange buffers (`nq * k` hits per rank and batch; query floats of the host entry point):
+    /// searches within the reserved sizes never allocate in the communicator.
+    pub fn reserve(&mut self, hits_per_rank: u64, query_floats: u64) -> io::Result<()> {
+        check(unsafe { vfsx_comm_reserve(self.h, hits_per_rank, query_floats) })
+    }
+    /// Device / pinned allocations made by this communicator so far.
+    pub fn alloc_count(&self) -> u64 {
+        unsafe { vfsx_comm_alloc_count(self.h) }
+    }
 
     /// Local scan + ncclAllGather + merge, device buffers, enqueued on `stream`.
     ///
@@ -485,6 +496,9 @@ impl Ranker {
     /// The same search over a row-sharded store: `shard` is this rank's contiguous range of the scan order,
     /// every rank calls with the same query and receives the same global ranking
     /// (local scan -> ncclAllGather -> merge by (distance, global row)).
+    /// A collective: the argument checks below are the same on every rank (same query, same `dim` on every
+    /// shard), so either every rank returns early or none does; a rank whose local scan fails later still joins
+    /// the all-gather (with an empty list) before it reports -- see `vfsx_search_sharded` in include/vfsx.h.
     pub fn search_sharded(
         &mut self, query: &[f32], num_vectors_per_iteration: usize, result_limit: Option<usize>, shard: &mut Corpus,
         comm: &mut Comm,

@@ -256,3 +256,46 @@ def test_searches_on_different_streams_share_the_workspaces_safely(oracle):
         oi, od, _ = want[i % 2]
         assert (ids[i] == oi).all() and (bits(dist[i]) == bits(od)).all()
     c.close()
+
+
+def test_search_after_the_previous_stream_was_destroyed():
+    """A host that makes a stream per request: search on stream A, destroy A, search on stream B.  The corpus
+    remembers the previous search's stream to order the shared workspaces; a dead handle there must not fail this
+    search or wedge the corpus (chain_search_stream)."""
+    import torch
+    import vfs_amd
+    from vfs_amd import sharded
+    hip = C.CDLL("libamdhip64.so")  # the runtime torch already loaded
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(5)
+    n, d, k = 50000, 32, 10
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    q = rng.uniform(-1, 1, (1, d)).astype(np.float32)
+    c = vfs_amd.Corpus(d)
+    c.append(rows)
+    dq = torch.from_numpy(q).cuda()
+    outs = torch.zeros((6, k, 6), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(6):
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        c.search_device(dq.data_ptr(), 1, k, 0, outs[i].data_ptr(), s.value)
+        assert hip.hipStreamSynchronize(s) == 0
+        assert hip.hipStreamDestroy(s) == 0  # the next search meets a dead `last_search_stream`
+    c.search_device(dq.data_ptr(), 1, k, 0, outs[0].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ids, dist, cnt = sharded.hits_to_arrays(outs)
+    for i in range(1, 6):
+        assert (ids[i] == ids[0]).all() and (bits(dist[i]) == bits(dist[0])).all() and cnt[i] == k
+    c.close()
+
+
+def test_vfsx_init_leaves_the_current_device_alone():
+    import torch
+    import vfs_amd
+    lib = vfs_amd.load()
+    before = torch.cuda.current_device()
+    assert lib.vfsx_init(lib.vfsx_device_count()) == 0
+    assert torch.cuda.current_device() == before

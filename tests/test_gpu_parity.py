@@ -223,3 +223,26 @@ def test_long_results_radix_select(oracle, quantize):
                 assert (gi[qi, :gc[qi]] == oi).all(), (k, metric, qi)
                 assert (_bits(gd[qi, :gc[qi]]) == _bits(od)).all(), (k, metric, qi)
     c.close()
+
+
+@pytest.mark.parametrize("n,balanced", [(16384 * 64, "1"), (600_037, "0")])
+def test_select_bound_with_more_lists_than_the_select_has_waves(oracle, monkeypatch, n, balanced):
+    """VFSX_BLOCKS_PER_CU=8 gives the scan up to 2048 workgroups = 2048 lists, twice what the select's 16 waves
+    hold as heads: the pruning bound may only count the waves that exist (with full = n_lists / 64
+    = 32 and k in 17..32 only 16 keys were vouched for and true hits were dropped)."""
+    import vfs_amd
+    monkeypatch.setenv("VFSX_BLOCKS_PER_CU", "8")
+    monkeypatch.setenv("VFSX_BALANCED_GRID", balanced)
+    d = 8
+    rows = oracle.synth_f32(77, 0, n, d)
+    queries = oracle.synth_f32(78, 0, 3, d)
+    c = vfs_amd.Corpus(d, capacity_rows=n)
+    c.append(rows)
+    for metric in (0, 1):
+        for k in (17, 20, 32, 64, 100, 128):
+            ids, dist, cnt = c.search_batch(queries, k, metric)  # 3 queries: one pass of 2 + one single
+            for qi in range(3):
+                oi, od, _ = oracle.topk_scan(rows, queries[qi], metric, k)
+                assert cnt[qi] == k and (ids[qi] == oi).all(), (metric, k, qi)
+                assert (dist[qi].view(np.uint32) == od.view(np.uint32)).all(), (metric, k, qi)
+    c.close()

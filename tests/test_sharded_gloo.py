@@ -68,3 +68,53 @@ def test_sharded_merge_matches_global(world):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _agree_worker(rank, world, port, ret, bad_rank):
+    """Comm.agree / Comm.bootstrap with a mocked communicator: vfsx_comm_init (Comm.__init__) must be entered by
+    every rank or by none."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vfs_amd import sharded
+        entered = []
+
+        class MockComm(sharded.Comm):
+            def __init__(self, rank, world, uid, device):  # stands where ncclCommInitRank would block
+                entered.append((rank, world, uid, device))
+                self._h = None
+
+            @staticmethod
+            def preflight(device):
+                return (False, "injected: device fell off the bus") if rank == bad_rank else (True, "")
+
+            @staticmethod
+            def unique_id():
+                return bytes(range(128))
+
+        try:
+            MockComm.bootstrap(rank)
+            ret[rank] = ("joined", entered[0][2] == bytes(range(128)) and entered[0][:2] == (rank, world))
+        except RuntimeError as e:
+            ret[rank] = ("refused", str(e), len(entered))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank", [-1, 0, 2])
+def test_comm_bootstrap_is_all_or_nothing(bad_rank):
+    world = 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_agree_worker, args=(world, port, ret, bad_rank), nprocs=world, join=True)
+    got = dict(ret)
+    if bad_rank < 0:
+        assert got == {r: ("joined", True) for r in range(world)}
+    else:
+        for r in range(world):  # the same refusal on every rank, naming the culprit; nobody entered the init
+            kind, msg, n_entered = got[r]
+            assert kind == "refused" and n_entered == 0
+            assert f"rank {bad_rank}: injected" in msg and "no rank enters ncclCommInitRank" in msg

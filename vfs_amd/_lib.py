@@ -19,7 +19,7 @@ ERR_INTERNAL = -6
 ERR_NO_DEVICE = -7
 
 F32, I8 = 0, 1
-MAX_K = 1 << 20  # VFSX_MAX_K; results beyond 1024 hits take several corpus passes
+MAX_K = 1 << 20  # VFSX_MAX_K; results beyond 128 hits: one scan + a radix select over every row's key
 
 # every symbol include/vfsx.h declares
 SYMBOLS = (
@@ -33,6 +33,7 @@ SYMBOLS = (
     "vfsx_log_inspect", "vfsx_corpus_load_log", "vfsx_corpus_load_log_range", "vfsx_corpus_get_metadata_json",
     "vfsx_comm_unique_id", "vfsx_comm_init", "vfsx_comm_destroy", "vfsx_comm_rank", "vfsx_comm_world",
     "vfsx_comm_rccl_version", "vfsx_search_sharded", "vfsx_search_sharded_host", "vfsx_comm_merge_hits",
+    "vfsx_comm_reserve", "vfsx_comm_alloc_count",
 )
 COMM_ID_BYTES = 128
 
@@ -125,6 +126,9 @@ def load() -> C.CDLL:
     lib.vfsx_comm_destroy.argtypes = [vp]
     lib.vfsx_comm_rank.argtypes = [vp]
     lib.vfsx_comm_world.argtypes = [vp]
+    lib.vfsx_comm_reserve.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.vfsx_comm_alloc_count.restype = C.c_uint64
+    lib.vfsx_comm_alloc_count.argtypes = [vp]
     lib.vfsx_search_sharded.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]
     lib.vfsx_comm_merge_hits.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     lib.vfsx_search_sharded_host.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_int, u64p, f32p, u32p]

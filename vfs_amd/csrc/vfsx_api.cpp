@@ -23,14 +23,8 @@
 
 namespace {
 
-thread_local std::string g_last_error;
-
-struct VfsxError : std::runtime_error {
-    int code;
-    VfsxError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
-};
-
-[[noreturn]] void fail(int code, const std::string &msg) { throw VfsxError(code, msg); }
+using vfsx::fail;
+using vfsx::guarded;
 
 void hip_check(hipError_t e, const char *what)
 {
@@ -42,28 +36,6 @@ void hip_check(hipError_t e, const char *what)
     }
 }
 #define HIP_CHECK(x) hip_check((x), #x)
-
-template <typename F>
-int guarded(F &&f)
-{
-    try {
-        g_last_error.clear();
-        f();
-        return VFSX_OK;
-    } catch (const VfsxError &e) {
-        g_last_error = e.what();
-        return e.code;
-    } catch (const std::bad_alloc &) {
-        g_last_error = "out of host memory";
-        return VFSX_ERR_INTERNAL;
-    } catch (const std::exception &e) {
-        g_last_error = e.what();
-        return VFSX_ERR_INTERNAL;
-    } catch (...) {
-        g_last_error = "unknown failure";
-        return VFSX_ERR_INTERNAL;
-    }
-}
 
 uint64_t env_u64(const char *name, uint64_t dflt)
 {
@@ -110,10 +82,6 @@ struct DeviceBuf {
 };
 
 } // namespace
-
-namespace vfsx {
-void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
-} // namespace vfsx
 
 struct vfsx_corpus {
     int device = 0;
@@ -163,11 +131,7 @@ struct vfsx_corpus {
     uint32_t n_cus = 0;
 
     // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
-    struct RowMeta {
-        std::string name;
-        std::vector<std::string> tags;
-        std::string created_at;
-    };
+    using RowMeta = vfsx::RowMeta;
     std::vector<RowMeta> meta; // empty, or one entry per row
 
     // many-query batches on the matrix cores (vfsx_mfma.hip): bf16 mirror + workspaces
@@ -943,11 +907,22 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
 void chain_search_stream(vfsx_corpus *c, hipStream_t s)
 {
     if (c->searched && c->last_search_stream != s) {
+        // The previous stream is the CALLER's and may have been destroyed since (a stream per request).  Whatever
+        // happens below, this call's stream becomes the remembered one first: a failure here must not wedge every
+        // later search on the corpus behind a dead handle.
+        const hipStream_t prev = c->last_search_stream;
+        c->last_search_stream = s;
         use_device(c);
         if (!c->search_done)
             HIP_CHECK(hipEventCreateWithFlags(&c->search_done, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(c->search_done, c->last_search_stream));
-        HIP_CHECK(hipStreamWaitEvent(s, c->search_done, 0));
+        if (hipEventRecord(c->search_done, prev) == hipSuccess) {
+            HIP_CHECK(hipStreamWaitEvent(s, c->search_done, 0));
+        } else {
+            // hipStreamDestroy has drained that stream's work (it blocks on AMD); the device-wide wait covers a
+            // runtime that defers it instead.  The sticky error belongs to the dead handle, not to this call.
+            (void)hipGetLastError();
+            HIP_CHECK(hipDeviceSynchronize());
+        }
     }
     c->last_search_stream = s;
     c->searched = true;
@@ -1029,9 +1004,19 @@ void *scratch_for_device(int device)
         fail(VFSX_ERR_NO_DEVICE, "HIP device index out of range");
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (!g_scratch_ptr[device]) {
+        // the symbol's address is per device and is looked up with that device current; the caller's current
+        // device is put back afterwards (vfsx_init(n) must not leave device n - 1 selected on the caller's thread)
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
         HIP_CHECK(hipSetDevice(device));
         void *p = nullptr;
-        HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (prev >= 0 && prev != device)
+            (void)hipSetDevice(prev);
+        HIP_CHECK(e);
         if (!p)
             fail(VFSX_ERR_INTERNAL, "hipGetSymbolAddress returned a null address for the static workspace");
         g_scratch_ptr[device] = p;
@@ -1091,8 +1076,6 @@ int vfsx_init(int n_devices)
         }
     });
 }
-
-const char *vfsx_last_error(void) { return g_last_error.c_str(); }
 
 const char *vfsx_version(void) { return "vfsx 0.1 gfx950 rb64"; }
 
@@ -1360,29 +1343,6 @@ int vfsx_merge_hits_device(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, 
     });
 }
 
-int vfsx_merge_hits_host(const vfsx_hit *in, uint32_t n_lists, uint32_t nq, uint32_t k, vfsx_hit *out)
-{
-    return guarded([&] {
-        if (!in || !out || n_lists == 0 || k == 0)
-            fail(VFSX_ERR_INVALID_VECTOR, "bad merge arguments");
-        std::vector<vfsx_hit> tmp((size_t)n_lists * k);
-        for (uint32_t q = 0; q < nq; ++q) {
-            for (uint32_t l = 0; l < n_lists; ++l)
-                std::memcpy(&tmp[(size_t)l * k], &in[((size_t)l * nq + q) * k], k * sizeof(vfsx_hit));
-            std::stable_sort(tmp.begin(), tmp.end(), [](const vfsx_hit &a, const vfsx_hit &b) {
-                const uint32_t va = a.flags & 1u, vb = b.flags & 1u;
-                if (va != vb)
-                    return va > vb;
-                const uint32_t ka = vfsx::host_dist_key(a.dist), kb = vfsx::host_dist_key(b.dist);
-                if (ka != kb)
-                    return ka < kb;
-                return a.row < b.row;
-            });
-            std::memcpy(&out[(size_t)q * k], tmp.data(), k * sizeof(vfsx_hit));
-        }
-    });
-}
-
 int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
 {
     return guarded([&] {
@@ -1473,184 +1433,13 @@ int vfsx_corpus_scan_time_ms(vfsx_corpus *c, double *total_ms, uint64_t *launche
 } // extern "C"
 
 // ---- F1: ingest from the reference's on-disk log (serializer.rs:25-153) ---------------------
-// record = DE AD BE EF | u64-LE payload length | bincode 1.3 (fixint, little endian) of VFSVector:
-//   u32 variant (0 Dense, 1 Quantized) | u64 id | u64 n | n x f32 or n x i8 | [f32 scale_factor] |
-//   String name | Vec<String> tags | String created_at (RFC 3339)      (String = u64 length + bytes)
-namespace {
-
-struct MappedFile {
-    const uint8_t *p = nullptr;
-    size_t n = 0;
-    int fd = -1;
-    explicit MappedFile(const char *path)
-    {
-        fd = ::open(path, O_RDONLY);
-        if (fd < 0)
-            fail(VFSX_ERR_IO, std::string("cannot open ") + path + ": " + std::strerror(errno));
-        struct stat st;
-        if (fstat(fd, &st) != 0)
-            fail(VFSX_ERR_IO, std::string("cannot stat ") + path);
-        n = (size_t)st.st_size;
-        if (n) {
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED)
-                fail(VFSX_ERR_IO, std::string("cannot map ") + path);
-            p = (const uint8_t *)m;
-        }
-    }
-    ~MappedFile()
-    {
-        if (p)
-            munmap((void *)p, n);
-        if (fd >= 0)
-            ::close(fd);
-    }
-};
-
-struct LogRecord {
-    uint32_t variant = 0;
-    uint64_t id = 0;
-    uint64_t n = 0;
-    const uint8_t *values = nullptr; // n f32 (Dense) or n i8 (Quantized), unaligned
-    float scale = 0.f;
-    vfsx_corpus::RowMeta meta;
-};
-
-struct Cursor {
-    const uint8_t *p;
-    size_t left;
-    template <typename T>
-    T get()
-    {
-        if (left < sizeof(T))
-            fail(VFSX_ERR_SERIALIZATION, "record payload truncated");
-        T v;
-        std::memcpy(&v, p, sizeof(T));
-        p += sizeof(T);
-        left -= sizeof(T);
-        return v;
-    }
-    const uint8_t *bytes(uint64_t n)
-    {
-        if (left < n)
-            fail(VFSX_ERR_SERIALIZATION, "record payload truncated");
-        const uint8_t *r = p;
-        p += n;
-        left -= (size_t)n;
-        return r;
-    }
-    std::string str()
-    {
-        uint64_t n = get<uint64_t>();
-        const uint8_t *b = bytes(n);
-        return std::string((const char *)b, (size_t)n);
-    }
-};
-
-void decode_record(const uint8_t *payload, size_t len, LogRecord &r)
-{
-    Cursor c{payload, len};
-    r.variant = c.get<uint32_t>();
-    if (r.variant > 1)
-        fail(VFSX_ERR_SERIALIZATION, "unknown VFSVector variant " + std::to_string(r.variant));
-    r.id = c.get<uint64_t>();
-    r.n = c.get<uint64_t>();
-    if (r.n > len)
-        fail(VFSX_ERR_SERIALIZATION, "vector length exceeds the record");
-    r.values = c.bytes(r.n * (r.variant == 0 ? 4u : 1u));
-    r.scale = r.variant == 1 ? c.get<float>() : 0.f;
-    r.meta.name = c.str();
-    uint64_t nt = c.get<uint64_t>();
-    if (nt > len)
-        fail(VFSX_ERR_SERIALIZATION, "tag count exceeds the record");
-    r.meta.tags.clear();
-    for (uint64_t i = 0; i < nt; ++i)
-        r.meta.tags.push_back(c.str());
-    r.meta.created_at = c.str();
-}
-
-// Walks the file the way load_vectors does (serializer.rs:101-150), minus its 1 KiB window:
-// a marker starts a record, any other byte is skipped, an incomplete trailing record ends the scan.
-// Records with index < first are stepped over by their length only (not decoded); at most max_count
-// records are delivered.  Returns the number of records delivered.
-template <typename F>
-uint64_t walk_log(const MappedFile &f, F &&on_record, uint64_t first = 0, uint64_t max_count = ~0ull)
-{
-    static const uint8_t marker[4] = {0xDE, 0xAD, 0xBE, 0xEF}; // serializer.rs:13
-    size_t cur = 0;
-    uint64_t index = 0, count = 0;
-    LogRecord r;
-    while (cur + 4 <= f.n && count < max_count) {
-        if (std::memcmp(f.p + cur, marker, 4) != 0) {
-            ++cur; // serializer.rs:148
-            continue;
-        }
-        if (cur + 12 > f.n)
-            break; // serializer.rs:142-146
-        uint64_t len;
-        std::memcpy(&len, f.p + cur + 4, 8);
-        if (len > f.n - (cur + 12))
-            break; // serializer.rs:137-141
-        if (index >= first) {
-            decode_record(f.p + cur + 12, (size_t)len, r);
-            on_record(r);
-            ++count;
-        }
-        ++index;
-        cur += 12 + (size_t)len;
-    }
-    return count;
-}
-
-void json_escape(std::string &out, const std::string &s)
-{
-    out += '"';
-    for (unsigned char ch : s) {
-        switch (ch) {
-        case '"': out += "\\\""; break;
-        case '\\': out += "\\\\"; break;
-        case '\n': out += "\\n"; break;
-        case '\r': out += "\\r"; break;
-        case '\t': out += "\\t"; break;
-        default:
-            if (ch < 0x20) {
-                char b[8];
-                std::snprintf(b, sizeof b, "\\u%04x", ch);
-                out += b;
-            } else {
-                out += (char)ch;
-            }
-        }
-    }
-    out += '"';
-}
-
-} // namespace
+// The file walker and record decoder are host-only code in vfsx_host.cpp (built by g++, fuzzed under
+// ASan/UBSan); here the decoded records are staged in batches and appended to the device-resident corpus.
+using vfsx::LogRecord;
+using vfsx::MappedFile;
+using vfsx::json_escape;
 
 extern "C" {
-
-int vfsx_log_inspect(const char *path, vfsx_log_info *info)
-{
-    return guarded([&] {
-        if (!path || !info)
-            fail(VFSX_ERR_INVALID_VECTOR, "null argument");
-        MappedFile f(path);
-        vfsx_log_info out{};
-        bool first = true;
-        out.records = walk_log(f, [&](const LogRecord &r) {
-            if (first) {
-                out.dim = (uint32_t)r.n;
-                out.dtype = r.variant == 1 ? VFSX_I8 : VFSX_F32;
-                out.scale = r.scale;
-                out.first_id = r.id;
-                first = false;
-            }
-            out.last_id = r.id;
-        });
-        out.file_bytes = f.n;
-        *info = out;
-    });
-}
 
 int vfsx_corpus_load_log(vfsx_corpus *c, const char *path, uint64_t *n_loaded)
 {
@@ -1685,7 +1474,7 @@ int vfsx_corpus_load_log_range(vfsx_corpus *c, const char *path, uint64_t first_
             ids.clear();
             metas.clear();
         };
-        walk_log(f, [&](const LogRecord &r) {
+        vfsx::walk_log(f.p, f.n, [&](const LogRecord &r) {
             if (r.n != c->dim) // tcp.rs:307-312
                 fail(VFSX_ERR_INVALID_VECTOR, "Vector dimension mismatch. Expected " + std::to_string(c->dim) +
                                                   ", got " + std::to_string(r.n));

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "vfsx.h"
+#include "vfsx_host.h" // error plumbing, log walker, host_dist_key: the host-only part (vfsx_host.cpp, g++)
 
 namespace vfsx {
 
@@ -175,21 +176,5 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
                               const int *only_flagged, hipStream_t s);
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);
-
-// thread-local message behind vfsx_last_error() (vfsx_api.cpp), for the other host translation units
-void set_last_error(const char *msg);
-inline void set_last_error(const std::string &msg) { set_last_error(msg.c_str()); }
-
-// host helpers shared with the host merge
-inline uint32_t host_dist_key(float d)
-{
-    uint32_t b;
-    __builtin_memcpy(&b, &d, 4);
-    if ((b & 0x7fffffffu) > 0x7f800000u)
-        return 0xffffffffu; // NaN sorts last
-    if (b == 0x80000000u)
-        b = 0; // -0.0 == +0.0 (partial_cmp)
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
 
 } // namespace vfsx

@@ -362,7 +362,9 @@ __global__ __launch_bounds__(64 * WAVES) void select_kernel(const uint64_t *__re
         if (threadIdx.x == 0)
             s_bound = 0ull;
         __syncthreads();
-        const uint32_t full = n_lists / 64u, m = full ? (k + full - 1u) / full : 65u;
+        // (only this workgroup's WAVES waves hold heads here: lists beyond 64 * WAVES are walked later and cannot
+        // vouch for the bound -- VFSX_BLOCKS_PER_CU = 8 gives 2048 lists)
+        const uint32_t full = min(n_lists / 64u, (uint32_t)WAVES), m = full ? (k + full - 1u) / full : 65u;
         const uint32_t list = lbase + lane;
         const bool in = list < n_lists;
         uint64_t c[4];

@@ -63,21 +63,51 @@ class Comm:
         _lib.check(lib.vfsx_comm_unique_id(buf))
         return buf.raw
 
+    @staticmethod
+    def preflight(device: int):
+        """What this rank can check by itself before anyone enters the (uncancellable) ncclCommInitRank:
+        RCCL loads, the device exists.  Returns (ok, message)."""
+        try:
+            lib = _lib.load()
+            if lib.vfsx_comm_rccl_version() <= 0:
+                return False, "RCCL cannot be loaded: " + lib.vfsx_last_error().decode("utf-8", "replace")
+            n = lib.vfsx_device_count()
+            if not 0 <= int(device) < n:
+                return False, f"HIP device {device} is not visible ({n} device(s))"
+            return True, ""
+        except Exception as e:  # noqa: BLE001 -- reported to every rank by bootstrap
+            return False, f"{type(e).__name__}: {e}"
+
     @classmethod
-    def bootstrap(cls, device: int, group=None) -> "Comm":
+    def agree(cls, device: int, group=None) -> bytes:
+        """Collective over an existing torch.distributed group (any backend): every rank reports its pre-flight,
+        rank 0 adds the communicator id; returns the id, or raises THE SAME RuntimeError on every rank when any
+        rank failed -- so either all ranks go on to ncclCommInitRank or none does."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [None]
-        if rank == 0:  # a failure on rank 0 must not leave the other ranks waiting in the broadcast
+        ok, msg = cls.preflight(device)
+        uid = None
+        if rank == 0 and ok:
             try:
-                box = [(cls.unique_id(), None)]
+                uid = cls.unique_id()
             except Exception as e:  # noqa: BLE001 -- re-raised on every rank below
-                box = [(None, f"{type(e).__name__}: {e}")]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        uid, err = box[0]
-        if uid is None:
-            raise RuntimeError(f"vfsx_comm_unique_id failed on rank 0: {err}")
-        return cls(rank, world, uid, device)
+                ok, msg = False, f"vfsx_comm_unique_id: {type(e).__name__}: {e}"
+        reports = [None] * world
+        dist.all_gather_object(reports, (bool(ok), msg, uid), group=group)
+        bad = [f"rank {r}: {m}" for r, (o, m, _) in enumerate(reports) if not o]
+        if bad:
+            raise RuntimeError("vfsx_comm pre-flight failed, no rank enters ncclCommInitRank -- " + "; ".join(bad))
+        return reports[0][2]
+
+    @classmethod
+    def bootstrap(cls, device: int, group=None) -> "Comm":
+        """`agree`, then vfsx_comm_init on every rank.  A rank that cannot join raises in `agree`, on every rank
+        alike, before anybody is inside ncclCommInitRank (which has no way out while a peer is missing;
+        vfsx_comm_init's own watchdog, VFSX_COMM_INIT_TIMEOUT_S, bounds what is left: a rank that dies between
+        the agreement and the init)."""
+        import torch.distributed as dist
+        uid = cls.agree(device, group)
+        return cls(dist.get_rank(group), dist.get_world_size(group), uid, device)
 
     @property
     def handle(self):
@@ -103,6 +133,14 @@ class Comm:
             ids.ctypes.data_as(C.POINTER(C.c_uint64)), dist.ctypes.data_as(C.POINTER(C.c_float)),
             cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
         return ids, dist, cnt
+
+    def reserve(self, hits_per_rank: int, query_floats: int = 0) -> None:
+        """Widen the exchange buffers now, so that no later call allocates (vfsx_comm_reserve)."""
+        _lib.check(self._lib.vfsx_comm_reserve(self._h, int(hits_per_rank), int(query_floats)))
+
+    @property
+    def alloc_count(self) -> int:
+        return int(self._lib.vfsx_comm_alloc_count(self._h))
 
     def close(self) -> None:
         if getattr(self, "_h", None):
