@@ -247,6 +247,9 @@ int vfsx_search(vfsx_corpus *c, const float *queries, uint32_t nq, uint32_t k, i
  *   d_hits     device, nq*k vfsx_hit; entries past the valid count have flags = 0
  * Used by the multi-GPU path (local top-k -> all-gather -> vfsx_merge_hits_device)
  * and by the benchmark (inputs already resident in HBM).
+ * Searches on one corpus share its workspaces: a call on a different stream than the previous call's first waits
+ * for the whole device (hipDeviceSynchronize -- the previous stream may be gone by then and is never touched
+ * again), so a stream per request is safe, and a host that wants overlap uses one corpus handle per stream.
  */
 int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k,
                        int metric, vfsx_hit *d_hits, void *stream);

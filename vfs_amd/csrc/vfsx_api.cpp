@@ -106,9 +106,8 @@ struct vfsx_corpus {
     hipStream_t stream = nullptr; // ingest + host-API searches
     // the search workspaces below are shared by every search on this corpus: searches on different streams are
     // chained (the new stream waits for what the previous one had enqueued) instead of left to race
-    hipStream_t last_search_stream = nullptr;
+    hipStream_t last_search_stream = nullptr; // compared, never used: it may be a destroyed stream's handle
     bool searched = false;
-    hipEvent_t search_done = nullptr;
     // ingest staging (pinned host + device), double buffered
     size_t stage_bytes = 0;
     void *h_stage[2] = {nullptr, nullptr};
@@ -902,27 +901,18 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     }
 }
 
-// A search on a stream other than the previous search's: make it wait for everything that search enqueued
-// (both use the corpus' workspaces).  Costs nothing while the caller stays on one stream.
+// A search on a stream other than the previous search's: both use the corpus' workspaces, so the new one must
+// start after everything the previous one enqueued.  The previous stream is the CALLER's and may have been
+// destroyed since (a stream per request) -- and HIP does not survive hipEventRecord / hipStreamWaitEvent on a dead
+// handle (it faults in the runtime), so that handle is never touched again: the switch waits for the whole device
+// instead.  Costs nothing while the caller stays on one stream; a host that alternates streams on ONE corpus handle
+// pays a device-wide wait per switch (the contract is one search at a time per handle, include/vfsx.h).
 void chain_search_stream(vfsx_corpus *c, hipStream_t s)
 {
     if (c->searched && c->last_search_stream != s) {
-        // The previous stream is the CALLER's and may have been destroyed since (a stream per request).  Whatever
-        // happens below, this call's stream becomes the remembered one first: a failure here must not wedge every
-        // later search on the corpus behind a dead handle.
-        const hipStream_t prev = c->last_search_stream;
-        c->last_search_stream = s;
+        c->last_search_stream = s; // first: a failure below must not leave the old handle behind
         use_device(c);
-        if (!c->search_done)
-            HIP_CHECK(hipEventCreateWithFlags(&c->search_done, hipEventDisableTiming));
-        if (hipEventRecord(c->search_done, prev) == hipSuccess) {
-            HIP_CHECK(hipStreamWaitEvent(s, c->search_done, 0));
-        } else {
-            // hipStreamDestroy has drained that stream's work (it blocks on AMD); the device-wide wait covers a
-            // runtime that defers it instead.  The sticky error belongs to the dead handle, not to this call.
-            (void)hipGetLastError();
-            HIP_CHECK(hipDeviceSynchronize());
-        }
+        HIP_CHECK(hipDeviceSynchronize());
     }
     c->last_search_stream = s;
     c->searched = true;
@@ -1143,8 +1133,6 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
-    if (c->search_done)
-        (void)hipEventDestroy(c->search_done);
     for (auto &pe : c->prof_events) {
         (void)hipEventDestroy(pe.first);
         (void)hipEventDestroy(pe.second);
