@@ -1,5 +1,7 @@
 """Diagnostic (GPU box): per-K-step cycle split of mfma_prefilter256_kernel from a -DVFSX_EXP_STAMPS build.
-usage: VFSX_LIB_PATH=exp/stamps/libvfsx.so python tools/exp_stamps.py [rows] [dim] [nq] [int8]"""
+usage: VFSX_LIB_PATH=exp/stamps/libvfsx.so [VFSX_MFMA_PF=rv] python tools/exp_stamps.py [rows] [dim] [nq] [int8]
+(the rows-in-registers kernel mfma_prefilter_rv_kernel carries the same stamps; the last figure is the in-kernel clock:
+s_memtime cycles per s_memrealtime tick of 10 ns)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,6 +23,8 @@ for rep in range(3):
     lib.vfsx_exp_stamps.restype = ctypes.c_int
     lib.vfsx_exp_stamps(out, 1)
     vm, bar, body, fold, n, total, waves = [int(x) for x in out[:7]]
+    rt = int(out[7])
     print(f"rep {rep}: waves {waves} ksteps/wave {n / waves:.0f}  per K-step cycles: vmcnt-wait {vm / n:.0f}  barrier {bar / n:.0f}  "
-          f"body {body / n:.0f}  fold(per K-step avg) {fold / n:.0f}  wave total/kstep {total / n:.0f}", flush=True)
+          f"body {body / n:.0f}  fold(per K-step avg) {fold / n:.0f}  wave total/kstep {total / n:.0f}  "
+          f"clock {total / max(rt, 1) * 0.1:.3f} GHz", flush=True)
 c.close()

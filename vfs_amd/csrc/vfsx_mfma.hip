@@ -374,7 +374,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // one 32 x 32 MFMA on a 16-byte fragment pair: 16 bf16 k (f32 accumulators) or 32 int8 k (exact i32 accumulators)
 __device__ __forceinline__ f32x16 mfma_32x32(uint4 a, uint4 b, f32x16 c)
 {
+#ifdef VFSX_EXP_M16 // timing experiment (WRONG results): the same flops, bytes and registers on the 16x16x32 shape
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c1, 0, 0, 0);
+    c[0] = c0[0], c[1] = c0[1], c[2] = c0[2], c[3] = c0[3], c[4] = c1[0], c[5] = c1[1], c[6] = c1[2], c[7] = c1[3];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ i32x16 mfma_32x32(uint4 a, uint4 b, i32x16 c)
 {
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 
 #ifdef VFSX_EXP_STAMPS
     uint64_t st_vm = 0, st_bar = 0, st_body = 0, st_fold = 0, st_n = 0;
-    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+    const uint64_t st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
 #endif
     // Fragment registers: two sets, k-slice ks uses set ks & 1 (KU is even, so every K-step starts on set 0).
     // PREFETCH (NSTAGE >= 3): the fragments of k-slice ks + 1 are read while the MFMAs of k-slice ks run, ACROSS the
@@ -758,6 +767,7 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         atomicAdd(&exp_stamps[4], (unsigned long long)st_n);
         atomicAdd(&exp_stamps[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st_begin));
         atomicAdd(&exp_stamps[6], 1ull);
+        atomicAdd(&exp_stamps[7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - st_rbegin));
     }
 #endif
 
@@ -769,6 +779,421 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
             cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
             cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
             cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+        }
+    }
+}
+
+// ---- prefilter GEMM, rows in registers ("rv"): 256 rows x 256 queries per workgroup, 8 waves as 8 (M) x 1 (N) ------
+// What held mfma_prefilter256_kernel at ~0.5 of the matrix peak is the global -> LDS fill beside the MFMAs' own
+// ds_reads (profiles/r02/c4_analysis.md: 8 LDS-DMA pieces per wave and K-step, 60-185 issue cycles each, in front of
+// that wave's 32 MFMAs).  Here a wave owns 32 rows of the tile outright, so its row fragments never need to be
+// shared: the mirror (and an rb64 int8 corpus) is stored in fragment order, one global load per lane IS the A operand
+// of one MFMA k-slice -- 1 KiB contiguous (rb64: two 512-byte runs) per wave-instruction, global -> VGPR, no LDS.
+// Only the query operand goes through LDS, where all 8 waves read it: per K-step a wave issues 4 LDS-DMA pieces
+// (not 8) + 4 plain loads, the CU stages 32 KiB (not 64) into a 4-slot ring (4 x 32 KiB, three stages ahead), and a
+// wave reads 8 query fragments per 8 MFMAs (one row fragment x 8 query groups, 128 accumulator registers as before).
+// Ring protocol per K-step `it` (one barrier):
+//     s_waitcnt vmcnt(8)   this wave's ops older than the 8 of K-step it-1 (row fragments of it+1, pieces of stage
+//                          it+2) are done: the row fragments of K-step it and its pieces of the stages <= it+1
+//     s_barrier            => stages <= it+1 are visible to every wave; every wave is done reading stage it-1
+//     16 groups of {2 ds_read_b128 for group g+2, a VMEM op every other group, s_waitcnt lgkmcnt(4), 2 MFMAs}:
+//         VMEM ops: first the row fragments of K-step it+2 into register set (it+2) % 3, then this wave's 4 pieces of
+//                   stage it+3 into slot (it+3) % 4 = the slot of stage it-1
+//         the last two groups' look-ahead reads are the first fragments of stage it+1 (visible: see the barrier)
+// All loads that the ring counts are inline asm or laundered (hipcc would otherwise order every ds_read behind the
+// pending LDS-DMAs with vmcnt(0), and any plain VGPR load beside LDS-DMAs the same way); the waits carry the
+// registers they release as "+v" operands, so no MFMA can be scheduled above the wait that covers its fragments.
+// Candidate lists: bit for bit those of mfma_prefilter256_kernel (wave w covers what (wave_m, mi) = (w >> 2, w & 3)
+// covers there; the four waves of one wave_m merge their top-3 through LDS at the end, as in the skinny kernel).
+template <int MODE, bool I8>
+__global__ __launch_bounds__(512) void mfma_prefilter_rv_kernel(const uint4 *__restrict__ A, const uint4 *__restrict__ B,
+                                                                float *__restrict__ cand, uint32_t n_rows,
+                                                                uint32_t n_rowtiles, uint32_t KS, uint32_t n_qtiles,
+                                                                uint32_t nq, uint32_t n_lists, uint32_t strip_tiles,
+                                                                const float2 *__restrict__ rn2,
+                                                                const float *__restrict__ q_norm,
+                                                                const float *__restrict__ q_eps, uint32_t a_chunks,
+                                                                uint64_t a_bytes, const float *__restrict__ inv_rn,
+                                                                const float *__restrict__ q_scale, uint32_t qpx,
+                                                                uint32_t n_strips)
+{
+    constexpr uint32_t KU = 4u, NSLOT = 4u, TROWS = 256u, TQ = 256u, NI = 8u;
+    constexpr uint32_t SLOT_BYTES = NI * KU * 1024u; // 32 KiB: 8 query groups x 4 k-slices
+    __shared__ __align__(16) uint4 ring[NSLOT * SLOT_BYTES / 16u];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
+    const uint32_t wave_m = wave >> 2, mi = wave & 3u;
+
+    // XCD-aware mapping: as mfma_prefilter256_kernel
+    const uint32_t id = blockIdx.x, xcd = id & 7u, within = id >> 3;
+    const uint32_t n_groups = n_qtiles / qpx, lanes_x = 8u / n_groups;
+    const uint32_t qtile = (xcd % n_groups) * qpx + within % qpx;
+    const uint32_t strip = (within / qpx) * lanes_x + xcd / n_groups;
+    if (strip >= n_strips)
+        return;
+    const uint32_t tile0 = strip * strip_tiles;
+    const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
+    const uint32_t KT = KS / KU;
+    const uint32_t n_it = ntiles * KT;
+
+    // ---- row fragments: global -> VGPR ----
+    // bf16 mirror: 32-row group (tile * 8 + wave) is KS consecutive 1 KiB units; rb64 int8: row-block (tile * 4 +
+    // (wave >> 1)), rows 32 (wave & 1) .., k-slice = a chunk pair (2 KiB apart), lane l reads chunk (l >> 5) of row l & 31
+    const uint32_t lane16a = I8 ? (lane >> 5) * 1024u + (lane & 31u) * 16u : lane * 16u;
+    const uint32_t a_tile_bytes = I8 ? 4u * a_chunks * 1024u : 8u * KS * 1024u;
+    const uint32_t a_piece = I8 ? 2048u : 1024u;
+    const uintptr_t a_end = (uintptr_t)A + a_bytes;
+    uintptr_t a_base = (uintptr_t)A + (uintptr_t)tile0 * a_tile_bytes +
+                       (I8 ? (uintptr_t)(wave >> 1) * a_chunks * 1024u + (wave & 1u) * 512u : (uintptr_t)wave * KS * 1024u);
+    uint32_t a_idx = 0, a_koff = 0; // next K-step whose row fragments are to be loaded
+    const uint32_t a_kstep = KU * a_piece, a_kend = KT * a_kstep;
+    auto a_rsrc = [&]() -> u32x4 {
+        // raw buffer resource: base, stride 0, num_records (rb64: bounded by the allocation -- the K padding and the
+        // last tile's missing row-blocks read past it and must get zeros, not a fault), flags as make_buffer_rsrc
+        uint32_t bound = 0xffffffffu;
+        if (I8) {
+            const uintptr_t left = a_base < a_end ? a_end - a_base : 0;
+            bound = left < 0xffffffffu ? (uint32_t)left : 0xffffffffu;
+        }
+        u32x4 r;
+        r[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_base);
+        r[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)a_base >> 32)) & 0xffffu;
+        r[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound);
+        r[3] = 0x00020000u;
+        return r;
+    };
+    auto a_advance = [&]() {
+        if (a_idx + 1u < n_it) { // past the last K-step: stay (a redundant reload keeps the vmcnt arithmetic constant)
+            ++a_idx;
+            a_koff += a_kstep;
+            if (a_koff == a_kend) {
+                a_koff = 0;
+                a_base += a_tile_bytes;
+            }
+        }
+    };
+#define VFSX_RV_ALOAD(dst, rsrc, soff)                                                                             \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(lane16a), "s"(rsrc), "s"(soff) : "memory")
+
+    // ---- query pieces: LDS-DMA, wave w stages query group w (its KU k-slices: 4 KiB contiguous) ----
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)ring;
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((uintptr_t)B + ((uintptr_t)qtile * 8u + wave) * KS * 1024u), 0, 0xffffffff, 0x00020000);
+    const uint32_t lane16 = lane * 16u;
+    uint32_t b_idx = 0, b_koff = 0, b_slot = 0; // next stage to issue
+    auto b_piece = [&](uint32_t u) {
+        uint32_t a = ring_base + b_slot * SLOT_BYTES + (wave * KU + u) * 1024u;
+        asm volatile("" : "+s"(a)); // LDS destination laundered: see mfma_prefilter256_kernel
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void *)(uintptr_t)a, 16,
+                                                 (int)lane16, (int)(b_koff + u * 1024u), 0, 0);
+    };
+    auto b_advance = [&]() {
+        b_slot = (b_slot + 1u) & (NSLOT - 1u);
+        if (b_idx + 1u < n_it) {
+            ++b_idx;
+            b_koff += KU * 1024u;
+            if (b_koff == KS * 1024u)
+                b_koff = 0;
+        }
+    };
+
+    typename std::conditional<I8, i32x16, f32x16>::type acc[NI];
+#pragma unroll
+    for (uint32_t ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[ni][r] = 0;
+    const float ninf = __uint_as_float(0xff800000u);
+    float m1[NI], m2[NI], m3[NI];
+#pragma unroll
+    for (uint32_t ni = 0; ni < NI; ++ni)
+        m1[ni] = m2[ni] = m3[ni] = ninf;
+    uint32_t keep_mask = ~kIdxMask;
+    asm volatile("" : "+v"(keep_mask));
+    auto insert3 = [&](uint32_t ni, float sp) __attribute__((always_inline)) {
+        m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
+        m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
+    };
+    auto fold_tile = [&](auto ragged_c, uint32_t ts, uint32_t tile_row0) __attribute__((always_inline)) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
+        // MODE 1, per query column (as mfma_prefilter256_kernel): read here, once per tile, rather than held in 16
+        // registers through the K loop
+        float cq[NI], ce[NI];
+        if (MODE == 1) {
+#pragma unroll
+            for (uint32_t ni = 0; ni < NI; ++ni) {
+                const uint32_t q = qtile * TQ + ni * 32u + (lane & 31u);
+                cq[ni] = ce[ni] = 0.0f;
+                if (q < nq) {
+                    const float a2 = 2.0f * q_norm[q];
+                    cq[ni] = I8 ? a2 * q_scale[q] : a2;
+                    ce[ni] = I8 ? a2 * q_eps[q] : q_eps[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const uint32_t row4 = tile_row0 + wave_m * 128u + mi * 32u + 8u * (uint32_t)rq + 4u * (lane >> 5);
+            float bn[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) {
+                const float4 p0 = *(const float4 *)(rn2 + row4);
+                const float4 p1 = *(const float4 *)(rn2 + row4 + 2u);
+                bn[0] = p0.x, bs[0] = p0.y, bn[1] = p0.z, bs[1] = p0.w;
+                bn[2] = p1.x, bs[2] = p1.y, bn[3] = p1.z, bs[3] = p1.w;
+            }
+            float rf[4] = {0.f, 0.f, 0.f, 0.f};
+            if (I8) {
+                const float4 p = *(const float4 *)(inv_rn + row4);
+                rf[0] = p.x, rf[1] = p.y, rf[2] = p.z, rf[3] = p.w;
+                if (MODE == 1) {
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl)
+                        rf[rl] *= bn[rl];
+                }
+            }
+#pragma unroll
+            for (int rl = 0; rl < 4; ++rl) {
+                const int r = rq * 4 + rl;
+                // the index is wave-uniform (an SGPR): mask (VGPR) + index is ONE v_and_or_b32 per element.  A row beyond
+                // the corpus (only in the last, ragged tile) scores -inf: its mask keeps nothing of the score and its
+                // "index" is the bit pattern of -inf.
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ts << 6) | (mi << 4) | (uint32_t)r));
+                const bool valid = !RAGGED || row4 + (uint32_t)rl < n_rows;
+                const uint32_t km = RAGGED ? (valid ? keep_mask : 0u) : keep_mask;
+                const uint32_t ix = RAGGED ? (valid ? idx : 0xff800000u) : idx;
+#pragma unroll
+                for (uint32_t ni = 0; ni < NI; ++ni) {
+                    float v = (float)acc[ni][r];
+                    if (I8 && MODE == 1)
+                        v = __builtin_fmaf(v * rf[rl], cq[ni], __builtin_fmaf(bn[rl], ce[ni], -bs[rl]));
+                    else if (I8)
+                        v = v * rf[rl];
+                    else if (MODE == 1)
+                        v = cq[ni] * (bn[rl] * (v + ce[ni])) - bs[rl];
+                    insert3(ni, __uint_as_float((__float_as_uint(v) & km) | ix));
+                    acc[ni][r] = 0;
+                }
+            }
+        }
+    };
+
+    // Registers.  Row fragments: a ring of three sets (set = K-step % 3), loaded TWO K-steps ahead -- they stream from
+    // HBM / the Infinity Cache (each row tile is new to this XCD's L2 for the first workgroup that touches it), and a
+    // timing experiment puts them at 19 % of the kernel when they only have one K-step to arrive, against 6 % for the
+    // L2-resident query pieces (profiles/r03/c4_analysis.md).  Query fragments: a ring of three sets of 2 (one k-slice
+    // of two query groups), read two groups ahead of their MFMAs; 16 groups per K-step and 16 = 1 (mod 3), so group g
+    // of K-step `it` uses set (it + g) % 3: both rings turn with PH = it % 3 and everything below is static per PH.
+    u32x4 fa[3][4];
+    u32x4 fb[2][2];
+    uint32_t rd_cur = ring_base + lane16, rd_slot = 0;
+#define VFSX_RV_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // the 2 query fragments of group g = 4 ks + qq: query groups 2 qq, 2 qq + 1 at k-slice ks (LDS unit ni * KU + ks)
+#define VFSX_RV_READ_PAIR(set, addr, g)                                                                            \
+    do {                                                                                                           \
+        VFSX_RV_DSR(fb[set][0], addr, ((2 * ((g) % 4) + 0) * 4 + (g) / 4) * 1024);                                 \
+        VFSX_RV_DSR(fb[set][1], addr, ((2 * ((g) % 4) + 1) * 4 + (g) / 4) * 1024);                                 \
+    } while (0)
+#if defined(VFSX_EXP_RV) // timing experiments (WRONG results): 2 = no row loads in the loop, 3 = no query pieces
+#if VFSX_EXP_RV == 2
+#undef VFSX_RV_ALOAD
+#define VFSX_RV_ALOAD(dst, rsrc, soff) asm volatile("" : "+v"(dst) : "s"(rsrc), "s"(soff))
+#endif
+#endif
+
+#ifdef VFSX_EXP_STAMPS
+    uint64_t st_vm = 0, st_bar = 0, st_body = 0, st_fold = 0, st_n = 0;
+    const uint64_t st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto kstep = [&](auto ph_c) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        VFSX_STAMP(t0);
+        // all of this wave's operations but those of the previous K-step (4 row loads + 4 pieces) have completed:
+        // the row fragments of this K-step and this wave's pieces of the stages <= it+1
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(fa[PH][0]), "+v"(fa[PH][1]), "+v"(fa[PH][2]), "+v"(fa[PH][3])::"memory");
+        VFSX_STAMP(t1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        VFSX_STAMP(t2);
+        const u32x4 ra = a_rsrc();
+        const uint32_t ak = a_koff;
+        a_advance();
+        const uint32_t rd_next = ring_base + ((rd_slot + 1u) & (NSLOT - 1u)) * SLOT_BYTES + lane16;
+        // group g: the reads of group g + 2, one VMEM operation every other group (the row fragments of K-step it+2
+        // first, then this wave's pieces of stage it+3), the wait for this group's own reads, 2 MFMAs
+#define VFSX_RV_GROUP(g, VMEM)                                                                                      \
+    do {                                                                                                           \
+        constexpr int S_ = (g) & 1, N_ = ((g) + 1) & 1;                                                             \
+        if ((g) + 1 < 16)                                                                                          \
+            VFSX_RV_READ_PAIR(N_, rd_cur, ((g) + 1) % 16);                                                         \
+        else                                                                                                       \
+            VFSX_RV_READ_PAIR(N_, rd_next, ((g) + 1) % 16);                                                        \
+        VMEM;                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[S_][0]), "+v"(fb[S_][1])::"memory");                          \
+        acc[2 * ((g) % 4) + 0] = mfma_32x32(__builtin_bit_cast(uint4, fa[PH][(g) / 4]),                             \
+                                            __builtin_bit_cast(uint4, fb[S_][0]), acc[2 * ((g) % 4) + 0]);          \
+        acc[2 * ((g) % 4) + 1] = mfma_32x32(__builtin_bit_cast(uint4, fa[PH][(g) / 4]),                             \
+                                            __builtin_bit_cast(uint4, fb[S_][1]), acc[2 * ((g) % 4) + 1]);          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    } while (0)
+        constexpr int AN = (PH + 2) % 3;
+        VFSX_RV_GROUP(0, VFSX_RV_ALOAD(fa[AN][0], ra, ak + 0u * a_piece));
+        VFSX_RV_GROUP(1, (void)0);
+        VFSX_RV_GROUP(2, VFSX_RV_ALOAD(fa[AN][1], ra, ak + 1u * a_piece));
+        VFSX_RV_GROUP(3, (void)0);
+        VFSX_RV_GROUP(4, VFSX_RV_ALOAD(fa[AN][2], ra, ak + 2u * a_piece));
+        VFSX_RV_GROUP(5, (void)0);
+        VFSX_RV_GROUP(6, VFSX_RV_ALOAD(fa[AN][3], ra, ak + 3u * a_piece));
+        VFSX_RV_GROUP(7, (void)0);
+#if defined(VFSX_EXP_RV) && VFSX_EXP_RV == 3
+#define b_piece(u) ((void)0)
+#endif
+        VFSX_RV_GROUP(8, b_piece(0));
+        VFSX_RV_GROUP(9, (void)0);
+        VFSX_RV_GROUP(10, b_piece(1));
+        VFSX_RV_GROUP(11, (void)0);
+        VFSX_RV_GROUP(12, b_piece(2));
+        VFSX_RV_GROUP(13, (void)0);
+        VFSX_RV_GROUP(14, b_piece(3));
+        VFSX_RV_GROUP(15, (void)0);
+#if defined(VFSX_EXP_RV) && VFSX_EXP_RV == 3
+#undef b_piece
+#endif
+#undef VFSX_RV_GROUP
+        VFSX_STAMP(t3);
+#ifdef VFSX_EXP_STAMPS
+        st_vm += t1 - t0, st_bar += t2 - t1, st_body += t3 - t2, st_n += 1;
+#endif
+        b_advance();
+        rd_slot = (rd_slot + 1u) & (NSLOT - 1u);
+        rd_cur = rd_next;
+    };
+
+    // prologue: stages 0 and 1, the row fragments of K-steps 0 and 1, stage 2 -- the last eight outstanding operations
+    // are then 4 row loads + 4 pieces, as in the steady state
+#pragma unroll
+    for (uint32_t u = 0; u < KU; ++u)
+        b_piece(u);
+    b_advance();
+#pragma unroll
+    for (uint32_t u = 0; u < KU; ++u)
+        b_piece(u);
+    b_advance();
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const u32x4 ra = a_rsrc();
+        const uint32_t ak = a_koff;
+        a_advance();
+        VFSX_RV_ALOAD(fa[st][0], ra, ak + 0u * a_piece);
+        VFSX_RV_ALOAD(fa[st][1], ra, ak + 1u * a_piece);
+        VFSX_RV_ALOAD(fa[st][2], ra, ak + 2u * a_piece);
+        VFSX_RV_ALOAD(fa[st][3], ra, ak + 3u * a_piece);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < KU; ++u)
+        b_piece(u);
+    b_advance();
+    // stage 0 visible to everybody -> the query fragments of the first two groups
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    VFSX_RV_READ_PAIR(0, rd_cur, 0);
+
+    // Tile by tile: within a tile the rings turn with kt % 3 (static); a tile of KT K-steps leaves them turned by
+    // KT % 3, and behind the fold -- ~4 us of VALU work in which everything in flight lands anyway -- the two sets that
+    // hold the next K-steps' row fragments are moved back to sets 0 and 1, so that every tile starts at phase 0 and the
+    // fold exists at ONE site (three sites made hipcc spill 150+ registers into the loop).
+    const uint32_t k_rem = KT % 3u;
+    for (uint32_t ts = 0; ts < ntiles; ++ts) {
+        uint32_t kt = 0;
+        for (; kt + 3u <= KT; kt += 3u) {
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+        }
+#ifndef VFSX_RV_T1
+        if (k_rem >= 1u)
+            kstep(std::integral_constant<int, 0>{});
+        if (k_rem == 2u)
+            kstep(std::integral_constant<int, 1>{});
+#endif
+        VFSX_STAMP(tf);
+        const uint32_t tile_row0 = (tile0 + ts) * TROWS;
+        if (tile_row0 + TROWS > n_rows)
+            fold_tile(std::true_type{}, ts, tile_row0); // last, ragged tile: rows >= n_rows masked
+        else
+            fold_tile(std::false_type{}, ts, tile_row0);
+        if (k_rem != 0u) {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]),
+                           "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[2][2]), "+v"(fa[2][3])::"memory");
+            if (k_rem == 1u) { // next K-step's fragments sit in set 1, the one after in set 2
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fa[0][u] = fa[1][u];
+                    fa[1][u] = fa[2][u];
+                }
+            } else { // in set 2 and set 0
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fa[1][u] = fa[0][u];
+                    fa[0][u] = fa[2][u];
+                }
+            }
+        }
+#ifdef VFSX_EXP_STAMPS
+        st_fold += __builtin_amdgcn_s_memtime() - tf;
+#endif
+    }
+#undef VFSX_RV_READ_PAIR
+#undef VFSX_RV_DSR
+#undef VFSX_RV_ALOAD
+
+    // the redundant tail loads / stages and the last look-ahead reads must land before the ring is reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]),
+                   "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[2][2]), "+v"(fa[2][3]),
+                   "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])::"memory");
+    __syncthreads();
+#ifdef VFSX_EXP_STAMPS
+    if (lane == 0) {
+        atomicAdd(&exp_stamps[0], (unsigned long long)st_vm);
+        atomicAdd(&exp_stamps[1], (unsigned long long)st_bar);
+        atomicAdd(&exp_stamps[2], (unsigned long long)st_body);
+        atomicAdd(&exp_stamps[3], (unsigned long long)st_fold);
+        atomicAdd(&exp_stamps[4], (unsigned long long)st_n);
+        atomicAdd(&exp_stamps[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - st_begin));
+        atomicAdd(&exp_stamps[6], 1ull);
+        atomicAdd(&exp_stamps[7], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - st_rbegin));
+    }
+#endif
+
+    // merge the four waves of one wave_m: [wave][ni][3][64] floats in the (now idle) ring
+    float *xch = (float *)ring;
+#pragma unroll
+    for (uint32_t ni = 0; ni < NI; ++ni) {
+        xch[((wave * NI + ni) * 3u + 0u) * 64u + lane] = m1[ni];
+        xch[((wave * NI + ni) * 3u + 1u) * 64u + lane] = m2[ni];
+        xch[((wave * NI + ni) * 3u + 2u) * 64u + lane] = m3[ni];
+    }
+    __syncthreads();
+    if (mi == 0u) {
+        for (uint32_t w = wave + 1u; w < wave + 4u; ++w)
+#pragma unroll
+            for (uint32_t ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (uint32_t j = 0; j < 3u; ++j)
+                    insert3(ni, xch[((w * NI + ni) * 3u + j) * 64u + lane]);
+        const uint32_t list = strip * 4u + wave_m * 2u + (lane >> 5);
+#pragma unroll
+        for (uint32_t ni = 0; ni < NI; ++ni) {
+            const uint32_t q = qtile * TQ + ni * 32u + (lane & 31u);
+            if (q < nq) {
+                cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
+                cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
+                cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+            }
         }
     }
 }
@@ -1658,6 +2083,17 @@ hipError_t launch_mfma_mirror_i8(const uint4 *corpus, const float *row_norms, ui
     return hipGetLastError();
 }
 
+// which 256 x 256 prefilter: VFSX_MFMA_PF = "rv" (rows in registers, mfma_prefilter_rv_kernel) or "lds" (both operands
+// through LDS, mfma_prefilter256_kernel)
+static bool pf_rows_in_registers()
+{
+    static const bool rv = [] {
+        const char *e = std::getenv("VFSX_MFMA_PF");
+        return e ? (e[0] == 'r') : false;
+    }();
+    return rv;
+}
+
 // euclid != 0: Euclidean upper-bound epilogue; rn2 / q_norm / q_eps as in the kernel
 // Grid of mfma_prefilter256_kernel and its query tiles per XCD (see the kernel's mapping comment): the most query
 // tiles whose share of Q~ fits half an XCD's L2 (4 MiB) among the groupings the mapping allows, or VFSX_MFMA_QPX.
@@ -1720,6 +2156,18 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
 #undef VFSX_SKINNY
         return hipGetLastError();
     }
+    if (pf_rows_in_registers()) {
+#define VFSX_PFRV(MODE)                                                                                            \
+    hipLaunchKernelGGL((mfma_prefilter_rv_kernel<MODE, false>), grid, dim3(512), 0, s, mirror, qm, cand, n_rows,     \
+                       g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn, q_norm, q_eps, 0u,            \
+                       (uint64_t)0, (const float *)nullptr, (const float *)nullptr, qpx, g.n_strips)
+        if (euclid)
+            VFSX_PFRV(1);
+        else
+            VFSX_PFRV(0);
+#undef VFSX_PFRV
+        return hipGetLastError();
+    }
 #define VFSX_PF256(MODE)                                                                                           \
     hipLaunchKernelGGL((mfma_prefilter256_kernel<VFSX_PF_KU, VFSX_PF_NSTAGE, MODE, false>), grid, dim3(512), 0, s,  \
                        mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists, g.strip_tiles, rn,    \
@@ -1771,6 +2219,19 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
                 VFSX_SKINNY(0, 2);
         }
 #undef VFSX_SKINNY
+        return hipGetLastError();
+    }
+    if (pf_rows_in_registers()) {
+#define VFSX_PFRV(MODE)                                                                                            \
+    hipLaunchKernelGGL((mfma_prefilter_rv_kernel<MODE, true>), grid, dim3(512), 0, s, corpus,                        \
+                       (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, n_qtiles, nq, g.n_lists,          \
+                       g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks, corpus_bytes, inv_rn, q_scale,  \
+                       qpx, g.n_strips)
+        if (euclid)
+            VFSX_PFRV(1);
+        else
+            VFSX_PFRV(0);
+#undef VFSX_PFRV
         return hipGetLastError();
     }
     // g.ku == 2: K is an odd number of 128-k half-steps (dim <= 128, 257..384, ...): the 64-k K-step variant takes
