@@ -114,7 +114,15 @@ const char *vfsx_version(void);
  *   dtype          VFSX_F32 or VFSX_I8
  *   scale          QuantizedVector::scale_factor (vector.rs:33); the store always uses
  *                  127.0 (vector.rs:188).  Ignored for VFSX_F32.
- *   capacity_rows  rows to reserve in HBM up front (grows by doubling when exceeded)
+ *   capacity_rows  rows to back with memory up front.  The store grows past it without moving a row: the
+ *                  row data, norms and ids each live in ONE virtual address range reserved for the device's
+ *                  worth of rows, and memory is mapped behind it slab by slab (doubling up to 1 GiB per slab,
+ *                  then 1 GiB at a time; HIP virtual memory management) -- an append never copies what is
+ *                  stored, a store that was not sized up front can fill the card (round 2 reallocated twice
+ *                  the size and copied: a third of the card at most), and device addresses handed out earlier
+ *                  stay valid.  The reference's feed is an unbounded append (storage_manager.rs:139-157).
+ *                  Where the driver offers no virtual memory management (or VFSX_VMM=0) the arrays are single
+ *                  blocks that grow by reallocation and copy.
  * Rows are kept in scan order = insertion order = ascending id
  * (storage_manager.rs:139-157: flush order).  Returns NULL on failure.
  */
@@ -171,11 +179,20 @@ int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64
  * Benchmark utility (no reference counterpart): fills the corpus on the device
  * with `n` rows of the counter-based synthetic generator described in DESIGN.md
  * (element (i,j) <- splitmix64(seed + (row0+i)*dim + j), uniform in [-1,1); an
- * int8 corpus stores quantize(value, scale)).  The corpus must be empty; ids are
- * id0, id0+1, ...
+ * int8 corpus stores quantize(value, scale)).  The corpus must be empty (ids are id0, id0+1, ...) or
+ * hold implicit ids that id0 continues (id0 = first id + rows: filling in pieces).
  */
 int vfsx_corpus_fill_synthetic(vfsx_corpus *c, uint64_t seed, uint64_t row0, uint64_t n,
                                uint64_t id0);
+
+/*
+ * How the store is laid out in device memory right now (no reference counterpart): rows backed by memory, slabs
+ * behind the row data (0 = one hipMalloc block: no virtual memory management), bytes ever copied because an array
+ * grew (0 with slabs), device bytes mapped for the store's arrays (rows, norms, ids, batch-path operands).
+ * Any pointer may be NULL.
+ */
+int vfsx_corpus_storage_info(vfsx_corpus *c, uint64_t *capacity_rows, uint64_t *segments, uint64_t *copied_bytes,
+                             uint64_t *device_bytes);
 
 /* ---- ingest from an existing VFS data directory ------------ */
 

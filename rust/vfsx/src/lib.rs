@@ -62,6 +62,7 @@ extern "C" {
     pub fn vfsx_corpus_get_rows_raw(c: *mut VfsxCorpus, rows: *const u64, n: u64, out: *mut c_void) -> c_int;
     pub fn vfsx_corpus_get_ids(c: *mut VfsxCorpus, rows: *const u64, n: u64, out: *mut u64) -> c_int;
     pub fn vfsx_corpus_fill_synthetic(c: *mut VfsxCorpus, seed: u64, row0: u64, n: u64, id0: u64) -> c_int;
+    pub fn vfsx_corpus_storage_info(c: *mut VfsxCorpus, capacity_rows: *mut u64, segments: *mut u64, copied_bytes: *mut u64, device_bytes: *mut u64) -> c_int;
     // ---- ingest from a VFS data directory
     pub fn vfsx_log_inspect(path: *const c_char, info: *mut VfsxLogInfo) -> c_int;
     pub fn vfsx_corpus_load_log(c: *mut VfsxCorpus, path: *const c_char, n_loaded: *mut u64) -> c_int;

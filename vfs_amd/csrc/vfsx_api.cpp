@@ -81,6 +81,179 @@ struct DeviceBuf {
     }
 };
 
+// ---- segmented device arrays -------------------------------------------------------------------------------
+// The corpus, its norms and ids (and the int8 operands of the batch path) grow without ever moving a stored row:
+// one contiguous VIRTUAL range per array is reserved up front (hipMemAddressReserve: address space, no memory) and
+// physical slabs are created and mapped behind the part already in use as the store grows (hipMemCreate /
+// hipMemMap / hipMemSetAccess) -- first a slab of the declared capacity, then slabs that double the array up to
+// kSlabBytes each, then one kSlabBytes slab at a time.  The kernels keep seeing ONE base pointer and the rb64
+// indexing they always had (no slab table, no per-access indirection), growth costs a map call instead of
+// "allocate twice the size and copy" -- which capped a store that was not sized up front at a third of the
+// card (old block + new block live together) -- and device pointers handed out earlier (a captured HIP graph)
+// stay valid.  The reference's feed is an unbounded append (storage_manager.rs:139-157).
+// Where the driver refuses virtual memory management (VFSX_VMM=0 forces this), the array is one hipMalloc block
+// that grows by reallocation and copy, as in round 2.
+constexpr size_t kSlabBytes = 1ull << 30;
+
+struct VmArray {
+    char *base = nullptr;
+    size_t reserved = 0; // bytes of address space (VMM) -- 0: the hipMalloc fallback
+    size_t mapped = 0;   // bytes backed by memory, from base
+    int device = 0;
+    struct Slab {
+        hipMemGenericAllocationHandle_t h;
+        size_t off, bytes;
+    };
+    std::vector<Slab> slabs;
+    uint64_t grow_calls = 0, copy_bytes = 0; // (diagnostics: vfsx_corpus_storage_info)
+
+    static bool vmm_wanted()
+    {
+        static const bool on = [] {
+            const char *e = std::getenv("VFSX_VMM");
+            return !(e && e[0] == '0');
+        }();
+        return on;
+    }
+
+    // All slabs of one array have the SAME size, a power of two fixed at the first mapping: the first request rounded
+    // up, between min_slab and kSlabBytes.  This driver's hipMemSetAccess returns "invalid argument" for a slab whose
+    // size differs from its predecessors' in the same range (4, 4, 8 KiB; 2, 2, 4, 6 MiB; 2, 2, 4, 8, 16 MiB all failed
+    // at the last one, 64 x 2 MiB, 40 x 64 MiB and 6 x 1 GiB went through: tools/probe/vmm_probe.cpp), and the
+    // granularity it reports, 4 KiB, is not one to build on.
+    size_t min_slab = 2u << 20;
+    size_t slab = 0;
+
+    // reserve address space for at most `max_bytes`; on any failure the array silently becomes a hipMalloc block
+    void init(int dev, size_t max_bytes)
+    {
+        device = dev;
+        if (!vmm_wanted() || max_bytes == 0)
+            return;
+        const size_t want = (max_bytes + kSlabBytes - 1) / kSlabBytes * kSlabBytes;
+        void *p = nullptr;
+        if (hipMemAddressReserve(&p, want, kSlabBytes, nullptr, 0) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return;
+        }
+        base = (char *)p;
+        reserved = want;
+    }
+
+    // one more slab behind the mapped part: false (and nothing changed) when the driver refuses
+    bool map_slab(size_t bytes)
+    {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        Slab sl{};
+        sl.off = mapped;
+        sl.bytes = bytes;
+        if (hipMemCreate(&sl.h, bytes, &prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        hipError_t e = hipMemMap(base + mapped, bytes, 0, sl.h, 0);
+        if (e == hipSuccess) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(base + mapped, bytes, &acc, 1);
+            if (e != hipSuccess)
+                (void)hipMemUnmap(base + mapped, bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemRelease(sl.h);
+            return false;
+        }
+        slabs.push_back(sl);
+        mapped += bytes;
+        return true;
+    }
+
+    // the driver stopped mapping slabs: move what is stored into one hipMalloc block and carry on as the fallback
+    void demote(size_t want, size_t used, hipStream_t s)
+    {
+        const size_t cap = std::max(want, mapped * 2);
+        char *nb = nullptr;
+        HIP_CHECK(hipMalloc((void **)&nb, cap));
+        if (used) {
+            hipError_t e = hipMemcpyAsync(nb, base, used, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                (void)hipFree(nb);
+                HIP_CHECK(e);
+            }
+            copy_bytes += used;
+        }
+        release();
+        base = nb;
+        mapped = cap;
+    }
+
+    // make [0, want) usable; `used` = bytes that hold data (what a copy has to move), on stream s
+    void grow(size_t want, size_t used, hipStream_t s)
+    {
+        if (want <= mapped)
+            return;
+        ++grow_calls;
+        if (reserved) {
+            if (want > reserved)
+                fail(VFSX_ERR_MEMTABLE, "corpus exceeds the address range reserved for it (the device's memory size)");
+            if (!slab) {
+                slab = min_slab;
+                while (slab < want && slab < kSlabBytes)
+                    slab <<= 1;
+            }
+            while (mapped < want) {
+                if (mapped + slab > reserved || !map_slab(slab)) {
+                    demote(want, used, s);
+                    return;
+                }
+            }
+            return;
+        }
+        // fallback: one block, doubled and copied
+        const size_t cap = std::max(want, mapped * 2);
+        char *nb = nullptr;
+        HIP_CHECK(hipMalloc((void **)&nb, cap));
+        if (used) {
+            hipError_t e = hipMemcpyAsync(nb, base, used, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                (void)hipFree(nb);
+                HIP_CHECK(e);
+            }
+            copy_bytes += used;
+        }
+        if (base)
+            (void)hipFree(base);
+        base = nb;
+        mapped = cap;
+    }
+
+    void release()
+    {
+        if (reserved) {
+            for (const Slab &sl : slabs) {
+                (void)hipMemUnmap(base + sl.off, sl.bytes);
+                (void)hipMemRelease(sl.h);
+            }
+            (void)hipMemAddressFree(base, reserved);
+        } else if (base) {
+            (void)hipFree(base);
+        }
+        slabs.clear();
+        base = nullptr;
+        reserved = mapped = 0;
+        slab = 0;
+    }
+};
+
 } // namespace
 
 struct vfsx_corpus {
@@ -98,6 +271,11 @@ struct vfsx_corpus {
     std::vector<uint64_t> ids_host; // only when explicit_ids
     uint64_t max_id = 0;            // largest explicit id stored (implicit continuation: max_id + 1)
 
+    // the three arrays that grow with the store (VmArray: address range reserved once, memory mapped as it fills);
+    // d_corpus / d_norms / d_ids are their base addresses, which never change after the first mapping (VMM)
+    VmArray va_corpus, va_norms, va_ids;
+    VmArray va_mirror, va_rn2, va_inv; // the batch path's per-row operands (d_mirror, d_rn2, d_inv_rn), grown the same way
+    uint64_t max_rows = 0; // rows the reserved ranges can hold
     uint4 *d_corpus = nullptr;
     float *d_norms = nullptr;
     uint64_t *d_ids = nullptr;
@@ -198,54 +376,31 @@ void reserve_rows(vfsx_corpus *c, uint64_t want_rows)
         return;
     if (want_rows > 0xfffffffeull - 64u)
         fail(VFSX_ERR_MEMTABLE, "corpus shard limited to 2^32-66 rows per device");
-    uint64_t cap = std::max<uint64_t>(round_up64(want_rows), std::min<uint64_t>(c->capacity * 2, 0xffffff00ull));
-    cap = std::max<uint64_t>(cap, 64);
-    uint4 *nc = nullptr;
-    float *nn = nullptr;
-    uint64_t *ni = nullptr;
-    struct Guard { // a failed allocation / copy below must not leak the new blocks
-        uint4 *&a;
-        float *&b;
-        uint64_t *&c;
-        bool armed = true;
-        ~Guard()
-        {
-            if (!armed)
-                return;
-            if (a)
-                (void)hipFree(a);
-            if (b)
-                (void)hipFree(b);
-            if (c)
-                (void)hipFree(c);
-        }
-    } guard{nc, nn, ni};
-    HIP_CHECK(hipMalloc((void **)&nc, c->corpus_bytes(cap)));
-    HIP_CHECK(hipMalloc((void **)&nn, cap * sizeof(float)));
+    if (c->va_corpus.reserved && want_rows > c->max_rows)
+        fail(VFSX_ERR_MEMTABLE, "corpus of " + std::to_string(want_rows) + " rows exceeds the device's memory");
+    const uint64_t rows = std::max<uint64_t>(round_up64(want_rows), 64);
+    const size_t used_rows = (size_t)round_up64(c->n_rows);
+    // the corpus grows first; the rows its mapped bytes hold become the capacity the side arrays follow
+    c->va_corpus.grow(c->corpus_bytes(rows), c->corpus_bytes(used_rows), c->stream);
+    uint64_t cap = std::min<uint64_t>(c->va_corpus.mapped / c->block_bytes() * 64u, 0xffffff00ull);
+    if (c->va_corpus.reserved)
+        cap = std::min<uint64_t>(cap, c->max_rows);
+    const size_t norms_before = c->va_norms.mapped;
+    c->va_norms.grow(cap * sizeof(float), c->n_rows * sizeof(float), c->stream);
     if (c->explicit_ids)
-        HIP_CHECK(hipMalloc((void **)&ni, cap * sizeof(uint64_t)));
-    // rows past n_rows are read by the scan but masked (row < n_rows): any bytes will do
-    HIP_CHECK(hipMemsetAsync(nn, 0, cap * sizeof(float), c->stream));
-    if (c->n_rows) {
-        HIP_CHECK(hipMemcpyAsync(nc, c->d_corpus, c->corpus_bytes(round_up64(c->n_rows)),
-                                 hipMemcpyDeviceToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(nn, c->d_norms, c->n_rows * sizeof(float), hipMemcpyDeviceToDevice,
-                                 c->stream));
-        if (c->explicit_ids && c->d_ids)
-            HIP_CHECK(hipMemcpyAsync(ni, c->d_ids, c->n_rows * sizeof(uint64_t), hipMemcpyDeviceToDevice,
-                                     c->stream));
+        c->va_ids.grow(cap * sizeof(uint64_t), c->n_rows * sizeof(uint64_t), c->stream);
+    c->d_corpus = (uint4 *)c->va_corpus.base;
+    c->d_norms = (float *)c->va_norms.base;
+    c->d_ids = (uint64_t *)c->va_ids.base;
+    // rows past n_rows are read by the scan but masked (row < n_rows): any corpus bytes will do; their norms are zero
+    if (c->va_norms.reserved) {
+        if (c->va_norms.mapped > norms_before)
+            HIP_CHECK(hipMemsetAsync(c->va_norms.base + norms_before, 0, c->va_norms.mapped - norms_before, c->stream));
+    } else {
+        const size_t keep = c->n_rows * sizeof(float);
+        HIP_CHECK(hipMemsetAsync(c->va_norms.base + keep, 0, c->va_norms.mapped - keep, c->stream));
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    guard.armed = false;
-    if (c->d_corpus)
-        HIP_CHECK(hipFree(c->d_corpus));
-    if (c->d_norms)
-        HIP_CHECK(hipFree(c->d_norms));
-    if (c->d_ids)
-        HIP_CHECK(hipFree(c->d_ids));
-    c->d_corpus = nc;
-    c->d_norms = nn;
-    c->d_ids = ni;
     c->capacity = cap;
 }
 
@@ -296,15 +451,10 @@ void make_ids_explicit(vfsx_corpus *c)
     std::vector<uint64_t> ids(c->n_rows);
     for (uint64_t r = 0; r < c->n_rows; ++r)
         ids[r] = c->id_base + r;
-    uint64_t *d_ids = nullptr;
-    HIP_CHECK(hipMalloc((void **)&d_ids, std::max<uint64_t>(c->capacity, 64) * sizeof(uint64_t)));
-    if (c->n_rows) {
-        const hipError_t e = hipMemcpy(d_ids, ids.data(), c->n_rows * sizeof(uint64_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(d_ids);
-            HIP_CHECK(e);
-        }
-    }
+    c->va_ids.grow(std::max<uint64_t>(c->capacity, 64) * sizeof(uint64_t), 0, c->stream);
+    uint64_t *d_ids = (uint64_t *)c->va_ids.base;
+    if (c->n_rows)
+        HIP_CHECK(hipMemcpy(d_ids, ids.data(), c->n_rows * sizeof(uint64_t), hipMemcpyHostToDevice));
     c->ids_host.swap(ids);
     c->d_ids = d_ids;
     c->max_id = c->n_rows ? c->id_base + c->n_rows - 1 : 0;
@@ -622,12 +772,9 @@ void exact_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, ui
 
 void free_mirror(vfsx_corpus *c)
 {
-    if (c->d_mirror)
-        (void)hipFree(c->d_mirror);
-    if (c->d_rn2)
-        (void)hipFree(c->d_rn2);
-    if (c->d_inv_rn)
-        (void)hipFree(c->d_inv_rn);
+    c->va_mirror.release();
+    c->va_rn2.release();
+    c->va_inv.release();
     c->d_rn2 = nullptr;
     c->d_inv_rn = nullptr;
     c->rn2_rows = 0;
@@ -661,16 +808,27 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
         const size_t cap_pad = i8 ? (size_t)gc.n_rowtiles * 256u : n_pad;
         const size_t want = c->dtype == VFSX_I8 ? 0
                             : (mirror_is_i8(c) ? (cap_pad / 64u) * mirror_i8_chunks(c) * 1024u : g.mirror_bytes);
-        // appended rows on an int8 operand that was complete and good before: only rows [mirror_rows, n_rows)
+        // appended rows on an int8 operand that was complete and good before: only rows [mirror_rows, n_rows) -- the
+        // operands are segmented arrays like the corpus (VmArray), so growing them keeps what is already built
         uint32_t row0 = 0;
-        if (i8 && c->d_rn2 && c->mirror_rows > 0 && c->mirror_rows < c->n_rows && !c->mirror_bad &&
-            want <= c->mirror_bytes && n_pad <= c->rn2_rows)
+        if (i8 && c->d_rn2 && c->mirror_rows > 0 && c->mirror_rows < c->n_rows && !c->mirror_bad && c->mirror_bytes != 0)
             row0 = (uint32_t)c->mirror_rows;
-        if (want > c->mirror_bytes) {
-            free_mirror(c);
-            HIP_CHECK(hipMalloc((void **)&c->d_mirror, want));
-            c->mirror_bytes = want;
+        if (c->mirror_bytes == 0 && (c->va_mirror.base || c->va_rn2.base))
+            free_mirror(c); // the mirror's kind changed: start over
+        if (!c->va_rn2.base && !c->va_rn2.reserved) { // first use: address ranges for the device's worth of rows
+            const size_t rows_max = ((size_t)c->max_rows + 255u) / 256u * 256u;
+            if (c->va_corpus.reserved) {
+                c->va_mirror.min_slab = 64u << 20;
+                c->va_mirror.init(c->device, c->dtype == VFSX_I8 ? 0 : rows_max * ((size_t)g.k_pad + 16u) * 2u);
+                c->va_rn2.init(c->device, rows_max * 2u * sizeof(float));
+                c->va_inv.init(c->device, rows_max * sizeof(float));
+            }
         }
+        const size_t mirror_before = c->va_mirror.mapped, inv_before = c->va_inv.mapped;
+        if (want > c->va_mirror.mapped)
+            c->va_mirror.grow(want, row0 ? mirror_before : 0, s);
+        c->d_mirror = (uint4 *)c->va_mirror.base;
+        c->mirror_bytes = want ? c->va_mirror.mapped : 1; // (int8 stores keep no mirror: any non-zero value = "built")
         if (!c->d_mirror_stats)
             HIP_CHECK(hipMalloc((void **)&c->d_mirror_stats, 2 * sizeof(uint32_t)));
         uint32_t st0[2] = {0, 0};
@@ -679,22 +837,22 @@ void ensure_mirror(vfsx_corpus *c, hipStream_t s)
         HIP_CHECK(hipMemcpyAsync(c->d_mirror_stats, st0, sizeof(st0), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s)); // (st0 lives on this stack frame)
         if (cap_pad > c->rn2_rows) { // Euclidean batches: (b, b^2 (1 - gamma)) per row; int8 operands: the row factor
-            if (c->d_rn2)
-                (void)hipFree(c->d_rn2);
-            if (c->d_inv_rn)
-                (void)hipFree(c->d_inv_rn);
-            c->d_rn2 = nullptr;
-            c->d_inv_rn = nullptr;
-            c->rn2_rows = 0;
-            HIP_CHECK(hipMalloc((void **)&c->d_rn2, cap_pad * 2u * sizeof(float)));
-            HIP_CHECK(hipMalloc((void **)&c->d_inv_rn, cap_pad * sizeof(float)));
-            c->rn2_rows = cap_pad;
-            row0 = 0;
+            c->va_rn2.grow(cap_pad * 2u * sizeof(float), row0 ? c->rn2_rows * 2u * sizeof(float) : 0, s);
+            c->va_inv.grow(cap_pad * sizeof(float), row0 ? c->rn2_rows * sizeof(float) : 0, s);
+            c->rn2_rows = std::min(c->va_rn2.mapped / (2u * sizeof(float)), c->va_inv.mapped / sizeof(float));
+        }
+        c->d_rn2 = (float *)c->va_rn2.base;
+        c->d_inv_rn = (float *)c->va_inv.base;
+        if (row0 && mirror_is_i8(c)) { // what growth added starts at zero (rows beyond n_rows are read and masked)
+            if (c->va_mirror.mapped > mirror_before)
+                HIP_CHECK(hipMemsetAsync(c->va_mirror.base + mirror_before, 0, c->va_mirror.mapped - mirror_before, s));
+            if (c->va_inv.mapped > inv_before)
+                HIP_CHECK(hipMemsetAsync(c->va_inv.base + inv_before, 0, c->va_inv.mapped - inv_before, s));
         }
         if (mirror_is_i8(c)) {
             if (!row0) {
-                HIP_CHECK(hipMemsetAsync(c->d_mirror, 0, want, s)); // rows beyond n_rows are read (and masked)
-                HIP_CHECK(hipMemsetAsync(c->d_inv_rn, 0, c->rn2_rows * sizeof(float), s));
+                HIP_CHECK(hipMemsetAsync(c->d_mirror, 0, c->va_mirror.mapped, s)); // rows beyond n_rows are read (and masked)
+                HIP_CHECK(hipMemsetAsync(c->d_inv_rn, 0, c->va_inv.mapped, s));
             }
             HIP_CHECK(vfsx::launch_mfma_mirror_i8(c->d_corpus, c->d_norms, c->d_mirror, c->d_inv_rn, (uint32_t)c->n_rows,
                                                   c->d_chunks, mirror_i8_chunks(c), g.k_pad, c->d_mirror_stats, s, row0));
@@ -1115,6 +1273,22 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
             HIP_CHECK(vfsx::launch_lut(c->scale, c->d_lut, c->stream));
         else
             HIP_CHECK(hipMemsetAsync(c->d_lut, 0, 256 * sizeof(float), c->stream));
+        // address ranges for the arrays that grow with the store: as many rows as the device's memory could hold
+        {
+            const uint64_t by_mem = std::max<uint64_t>(64, (uint64_t)prop.totalGlobalMem / c->block_bytes() * 64u);
+            c->max_rows = std::min<uint64_t>(by_mem, 0xffffff00ull);
+            c->va_corpus.min_slab = 64u << 20; // row data: 64 MiB .. 1 GiB per slab; side arrays: 2 MiB .. 1 GiB
+            c->va_corpus.init(device, c->corpus_bytes(c->max_rows));
+            if (c->va_corpus.reserved) {
+                c->va_norms.init(device, c->max_rows * sizeof(float));
+                c->va_ids.init(device, c->max_rows * sizeof(uint64_t));
+                if (!c->va_norms.reserved || !c->va_ids.reserved) { // all three or none
+                    c->va_corpus.release();
+                    c->va_norms.release();
+                    c->va_ids.release();
+                }
+            }
+        }
         reserve_rows(c, std::max<uint64_t>(capacity_rows, 64));
         HIP_CHECK(hipStreamSynchronize(c->stream));
     });
@@ -1168,12 +1342,9 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->hits.release();
     c->row_idx.release();
     c->row_out.release();
-    if (c->d_corpus)
-        (void)hipFree(c->d_corpus);
-    if (c->d_norms)
-        (void)hipFree(c->d_norms);
-    if (c->d_ids)
-        (void)hipFree(c->d_ids);
+    c->va_corpus.release();
+    c->va_norms.release();
+    c->va_ids.release();
     if (c->d_lut)
         (void)hipFree(c->d_lut);
     if (c->stream)
@@ -1239,23 +1410,48 @@ int vfsx_corpus_fill_synthetic(vfsx_corpus *c, uint64_t seed, uint64_t row0, uin
 {
     return guarded([&] {
         checked(c);
-        if (c->n_rows != 0)
-            fail(VFSX_ERR_MEMTABLE, "fill_synthetic needs an empty corpus");
+        // an empty corpus, or one that holds implicit ids which id0 continues (appending in pieces: the growth tests)
+        if (c->n_rows != 0 && (c->explicit_ids || id0 != c->id_base + c->n_rows))
+            fail(VFSX_ERR_MEMTABLE, "fill_synthetic needs an empty corpus, or ids that continue the implicit run");
         if (n == 0)
             return;
         use_device(c);
-        reserve_rows(c, n);
+        const uint64_t at = c->n_rows;
+        reserve_rows(c, at + n);
         // keep each launch's grid below 2^31 blocks
         const uint64_t rows_per_launch = std::max<uint64_t>(64, ((1ull << 36) / ((uint64_t)c->d_chunks * 64u)) / 64u * 64u);
         for (uint64_t r = 0; r < n; r += rows_per_launch) {
             const uint64_t take = std::min(rows_per_launch, n - r);
-            HIP_CHECK(vfsx::launch_fill_synthetic(c->dtype, c->d_corpus, c->dim, c->d_chunks, r, take, seed,
+            HIP_CHECK(vfsx::launch_fill_synthetic(c->dtype, c->d_corpus, c->dim, c->d_chunks, at + r, take, seed,
                                                   row0 + r, c->scale, c->stream));
         }
-        HIP_CHECK(vfsx::launch_row_norms(c->dtype, c->d_corpus, c->d_chunks, c->d_lut, 0, n, c->d_norms, c->stream));
+        HIP_CHECK(vfsx::launch_row_norms(c->dtype, c->d_corpus, c->d_chunks, c->d_lut, at, n, c->d_norms, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
-        c->id_base = id0;
-        c->n_rows = n;
+        if (at == 0)
+            c->id_base = id0;
+        c->n_rows = at + n;
+    });
+}
+
+int vfsx_corpus_storage_info(vfsx_corpus *c, uint64_t *capacity_rows, uint64_t *segments, uint64_t *copied_bytes,
+                             uint64_t *device_bytes)
+{
+    return guarded([&] {
+        checked(c);
+        const VmArray *all[] = {&c->va_corpus, &c->va_norms, &c->va_ids, &c->va_mirror, &c->va_rn2, &c->va_inv};
+        uint64_t copied = 0, bytes = 0;
+        for (const VmArray *a : all) {
+            copied += a->copy_bytes;
+            bytes += a->mapped;
+        }
+        if (capacity_rows)
+            *capacity_rows = c->capacity;
+        if (segments) // slabs behind the row data (0: the driver gave no virtual memory management; one block, grown by copy)
+            *segments = c->va_corpus.reserved ? c->va_corpus.slabs.size() : 0;
+        if (copied_bytes)
+            *copied_bytes = copied;
+        if (device_bytes)
+            *device_bytes = bytes;
     });
 }
 

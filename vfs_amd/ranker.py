@@ -143,6 +143,13 @@ class Corpus:
     def fill_synthetic(self, seed: int, n: int, row0: int = 0, id0: int = 1) -> None:
         _lib.check(self._lib.vfsx_corpus_fill_synthetic(self._h, seed, row0, n, id0))
 
+    def storage_info(self) -> dict:
+        """Rows backed by memory, slabs behind the row data (0 = one block grown by copy), bytes copied by growth,
+        device bytes mapped (vfsx_corpus_storage_info)."""
+        cap, seg, cp, dev = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self._lib.vfsx_corpus_storage_info(self._h, C.byref(cap), C.byref(seg), C.byref(cp), C.byref(dev)))
+        return {"capacity_rows": cap.value, "segments": seg.value, "copied_bytes": cp.value, "device_bytes": dev.value}
+
     def set_row_base(self, row_base: int) -> None:
         _lib.check(self._lib.vfsx_corpus_set_row_base(self._h, int(row_base)))
 
