@@ -150,6 +150,29 @@ int vfsx_corpus_append(vfsx_corpus *c, const void *rows, const uint64_t *ids, ui
 int vfsx_corpus_append_quantize(vfsx_corpus *c, const float *rows, const uint64_t *ids,
                                 uint64_t n);
 
+/*
+ * Online inserts (register_vector_from_vec one at a time, storage_manager.rs:317-335; the reference keeps up to 10
+ * in its memtable, :12,310-312).  Off by default: every append reaches the device before it returns.  With
+ * max_pending_rows > 0, appends of <= 16 rows are staged in host memory and committed together -- one H2D copy, one
+ * layout / quantize launch, one norm launch for the lot -- as soon as max_pending_rows of them wait, and before
+ * ANYTHING reads the store (every search, get_rows / get_ids, larger appends, log loads, enable_mfma ...): a vector
+ * is searchable the moment its append returns, exactly once (the reference shows memtable vectors twice).
+ * An error of the deferred device work (out of memory) is reported by the call that commits and drops the staged rows.
+ * vfsx_corpus_rows counts staged rows.  vfsx_search_device_noalloc never commits: with rows staged it fails with
+ * VFSX_ERR_MEMTABLE -- call vfsx_corpus_commit first.  0 switches batching off and commits.
+ */
+int vfsx_corpus_set_insert_batch(vfsx_corpus *c, uint32_t max_pending_rows);
+/* Commit the staged appends now (no-op when none wait). */
+int vfsx_corpus_commit(vfsx_corpus *c);
+
+/*
+ * The store's quantization rule on the host: out[i] = (values[i] * scale).round() as i8 (Vector::quantize(Some(scale)),
+ * vector.rs:94-108: f32 multiply, round half away from zero, saturating cast, NaN -> 0) -- the bytes
+ * vfsx_corpus_append_quantize leaves in HBM for the same input (tests/test_gpu_api.py compares them), for hosts that
+ * write the stored form to the reference's log (storage_manager.rs:139-157) without reading it back.  Needs no GPU.
+ */
+int vfsx_quantize_rows_host(const float *values, uint64_t n, float scale, int8_t *out);
+
 /* Number of rows currently searchable. */
 uint64_t vfsx_corpus_rows(const vfsx_corpus *c);
 uint32_t vfsx_corpus_dim(const vfsx_corpus *c);

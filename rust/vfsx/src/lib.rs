@@ -62,6 +62,9 @@ extern "C" {
     pub fn vfsx_corpus_get_rows_raw(c: *mut VfsxCorpus, rows: *const u64, n: u64, out: *mut c_void) -> c_int;
     pub fn vfsx_corpus_get_ids(c: *mut VfsxCorpus, rows: *const u64, n: u64, out: *mut u64) -> c_int;
     pub fn vfsx_corpus_fill_synthetic(c: *mut VfsxCorpus, seed: u64, row0: u64, n: u64, id0: u64) -> c_int;
+    pub fn vfsx_quantize_rows_host(values: *const f32, n: u64, scale: f32, out: *mut i8) -> c_int;
+    pub fn vfsx_corpus_set_insert_batch(c: *mut VfsxCorpus, max_pending_rows: u32) -> c_int;
+    pub fn vfsx_corpus_commit(c: *mut VfsxCorpus) -> c_int;
     pub fn vfsx_corpus_storage_info(c: *mut VfsxCorpus, capacity_rows: *mut u64, segments: *mut u64, copied_bytes: *mut u64, device_bytes: *mut u64) -> c_int;
     // ---- ingest from a VFS data directory
     pub fn vfsx_log_inspect(path: *const c_char, info: *mut VfsxLogInfo) -> c_int;

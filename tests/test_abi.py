@@ -96,7 +96,7 @@ def test_split_rows_contiguous():
 _C_TO_RUST = {
     "void": "()", "int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64",
     "const char *": "*const c_char", "char *": "*mut c_char", "void *": "*mut c_void", "const void *": "*const c_void",
-    "const float *": "*const f32", "float *": "*mut f32", "double *": "*mut f64",
+    "const float *": "*const f32", "float *": "*mut f32", "int8_t *": "*mut i8", "double *": "*mut f64",
     "const uint64_t *": "*const u64", "uint64_t *": "*mut u64", "uint32_t *": "*mut u32", "int *": "*mut c_int",
     "vfsx_corpus *": "*mut VfsxCorpus", "const vfsx_corpus *": "*const VfsxCorpus",
     "vfsx_comm *": "*mut VfsxComm", "const vfsx_comm *": "*const VfsxComm",

@@ -299,3 +299,70 @@ def test_vfsx_init_leaves_the_current_device_alone():
     before = torch.cuda.current_device()
     assert lib.vfsx_init(lib.vfsx_device_count()) == 0
     assert torch.cuda.current_device() == before
+
+
+def test_insert_batching_keeps_every_row_searchable_at_once(oracle):
+    """vfsx_corpus_set_insert_batch: one-row appends are staged on the host and committed together, but every read
+    of the store commits first -- a vector is searchable the moment its append returns, once, in scan order, with
+    the ids it was given (storage_manager.rs:317-335 / SURVEY F3)."""
+    import torch
+    import vfs_amd
+    rng = np.random.default_rng(44)
+    d = 24
+    rows = rng.uniform(-1, 1, (3000, d)).astype(np.float32)
+    for quantize in (False, True):
+        c = vfs_amd.Corpus(d, quantize=quantize)
+        c.set_insert_batch(512)
+        ref = oracle.quantize(rows, 127.0) if quantize else rows
+        for i in range(700):  # single rows, explicit ids
+            c.append_f32(rows[i:i + 1], ids=[1000 + i])
+            assert len(c) == i + 1
+            if i in (0, 1, 9, 511, 512, 699):  # searched while rows wait: the newest row is its own nearest neighbour
+                probe = ref[i].astype(np.float32) / np.float32(127.0) if quantize else rows[i]
+                ids, dist, cnt = c.search_batch(probe, 1, 0)
+                assert cnt[0] == 1 and dist[0, 0] == 0.0 and ids[0, 0] == 1000 + int(np.flatnonzero((ref[:i + 1] == ref[i]).all(axis=1))[0])
+        c.append_f32(rows[700:716], ids=np.arange(1700, 1716, dtype=np.uint64))  # 16 rows: still staged
+        c.append_f32(rows[716:2000], ids=np.arange(1716, 3000, dtype=np.uint64))  # a large append commits what waits, in order
+        for i in range(2000, 2010):
+            c.append_f32(rows[i:i + 1])  # no ids on a store that has explicit ones: continue after the largest
+        assert len(c) == 2010 and c.get_ids([0, 699, 700, 1999, 2000, 2009]).tolist() == [1000, 1699, 1700, 2999, 3000, 3009]
+        q = rng.uniform(-1, 1, d).astype(np.float32)
+        for metric in (0, 1):
+            ids, dist, cnt = c.search_batch(q, 10, metric)
+            oi, od, op = oracle.topk_scan(ref[:2010], q, metric, 10)
+            assert (ids[0] == op + 1000).all() and (bits(dist[0]) == bits(od)).all()
+        # the entry point that allocates nothing never commits: it refuses while rows wait
+        c.append_f32(rows[2010:2011])
+        dq = torch.from_numpy(q[None, :]).cuda()
+        out = torch.zeros((1, 10, 6), dtype=torch.int32, device="cuda")
+        with pytest.raises(vfs_amd.VfsxError) as e:
+            c.search_device_noalloc(dq.data_ptr(), 1, 10, 0, out.data_ptr(), 0)
+        assert e.value.code == vfs_amd._lib.ERR_MEMTABLE and "vfsx_corpus_commit" in str(e.value)
+        c.commit()
+        c.search_device_noalloc(dq.data_ptr(), 1, 10, 0, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        c.set_insert_batch(0)
+        c.append_f32(rows[2011:2012])
+        assert len(c) == 2012
+        c.close()
+
+
+def test_host_quantizer_equals_the_device_quantizer(oracle):
+    """vfsx_quantize_rows_host (what the server writes to the log) == the bytes vfsx_corpus_append_quantize leaves in
+    HBM == the oracle's quantize, on halves, saturation, NaN, infinities, subnormals and random values."""
+    import vfs_amd
+    rng = np.random.default_rng(3)
+    special = np.array([0.5 / 127, -0.5 / 127, 1.5 / 127, 2.5 / 127, -2.5 / 127, 63.5 / 127, 0.49999997 / 127, 1.0, -1.0,
+                        1.004, -1.008, 2.0, -2.0, 1e9, -1e9, np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-45, -1e-45,
+                        126.5 / 127, 127.5 / 127, -127.5 / 127, -128.5 / 127], dtype=np.float32)
+    vals = np.concatenate([special, rng.uniform(-1.2, 1.2, 64 * 300 - special.size).astype(np.float32)]).reshape(300, 64)
+    vals[1:, :] += (rng.integers(-128, 128, vals[1:, :].shape) + 0.5).astype(np.float32) / np.float32(127) * (rng.random(vals[1:, :].shape) < 0.2)
+    lib = vfs_amd.load()
+    host = np.empty(vals.shape, dtype=np.int8)
+    vfs_amd._lib.check(lib.vfsx_quantize_rows_host(vals.ctypes.data_as(C.POINTER(C.c_float)), vals.size, 127.0,
+                                                   host.ctypes.data_as(C.POINTER(C.c_int8))))
+    c = vfs_amd.Corpus(64, quantize=True)
+    c.append_f32(vals)
+    dev = c.get_rows_raw(np.arange(300))
+    assert (host == dev).all() and (host == oracle.quantize(vals, 127.0)).all()
+    c.close()

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vfs_amd import server
 
 rng = np.random.default_rng(0)
-for d, quant in ((16, True), (768, False), (768, True)):
+for d, quant in ((16, True), (16, True), (768, False), (768, True)):  # (the first case warms the process up: not printed)
     with tempfile.TemporaryDirectory() as tmp:
         st = server.ServerState(d, quant, "bench", state_dir=os.path.join(tmp, "state"), data_dir=os.path.join(tmp, "data"))
         os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
@@ -32,7 +32,31 @@ for d, quant in ((16, True), (768, False), (768, True)):
         lat = np.array(lat) * 1e6
         flush = lat[9::10]  # every 10th insert flushes the memtable to the log
         plain = np.delete(lat, np.arange(9, len(lat), 10))
-        print(f"d={d} {'int8 (device quantize)' if quant else 'f32'} store: {len(lat) / dt:.0f} inserts/s; "
-              f"median {np.median(plain):.0f} us per insert, {np.median(flush):.0f} us on the flushing 10th "
-              f"(searchable at once; {len(st.corpus)} rows resident)", flush=True)
+        first_case = "warm" not in globals()
+        warm = True
+        if not first_case:
+            print(f"d={d} {'int8 (device quantize)' if quant else 'f32'} store: {len(lat) / dt:.0f} inserts/s; "
+                  f"median {np.median(plain):.0f} us per insert, {np.median(flush):.0f} us on the flushing 10th, "
+                  f"p99 {np.percentile(lat, 99):.0f} us, max {lat.max():.0f} us "
+                  f"(searchable at once; {len(st.corpus)} rows resident)", flush=True)
         st.corpus.close()
+
+# the engine side alone: one-row vfsx_corpus_append[_quantize] calls through ctypes, every append committed at once
+# (round 2's behaviour) against appends staged on the host and committed 4096 at a time (vfsx_corpus_set_insert_batch)
+import vfs_amd
+for d, quant in ((16, True), (768, False), (768, True)):
+    rows = rng.uniform(-1, 1, (20000, d)).astype(np.float32)
+    for batch in (0, 4096):
+        c = vfs_amd.Corpus(d, quantize=quant)
+        c.set_insert_batch(batch)
+        for v in rows[:200]:
+            c.append_f32(v[None, :])
+        t0 = time.perf_counter()
+        for v in rows[200:]:
+            c.append_f32(v[None, :])
+        c.commit()
+        dt = time.perf_counter() - t0
+        ids, dist, cnt = c.search_batch(rows[-1] if not quant else rows[-1], 1, 0)
+        print(f"C ABI, d={d} {'int8' if quant else 'f32'}, insert batch {batch}: {(len(rows) - 200) / dt:.0f} one-row appends/s "
+              f"({len(c)} rows resident, last row found: id {int(ids[0, 0])})", flush=True)
+        c.close()

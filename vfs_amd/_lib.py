@@ -34,6 +34,7 @@ SYMBOLS = (
     "vfsx_comm_unique_id", "vfsx_comm_init", "vfsx_comm_destroy", "vfsx_comm_rank", "vfsx_comm_world",
     "vfsx_comm_rccl_version", "vfsx_search_sharded", "vfsx_search_sharded_host", "vfsx_comm_merge_hits",
     "vfsx_comm_reserve", "vfsx_comm_alloc_count", "vfsx_corpus_storage_info",
+    "vfsx_corpus_set_insert_batch", "vfsx_corpus_commit", "vfsx_quantize_rows_host",
 )
 COMM_ID_BYTES = 128
 
@@ -105,6 +106,9 @@ def load() -> C.CDLL:
     lib.vfsx_corpus_get_rows_raw.argtypes = [vp, u64p, C.c_uint64, vp]
     lib.vfsx_corpus_get_ids.argtypes = [vp, u64p, C.c_uint64, u64p]
     lib.vfsx_corpus_fill_synthetic.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.vfsx_corpus_set_insert_batch.argtypes = [vp, C.c_uint32]
+    lib.vfsx_corpus_commit.argtypes = [vp]
+    lib.vfsx_quantize_rows_host.argtypes = [f32p, C.c_uint64, C.c_float, C.POINTER(C.c_int8)]
     lib.vfsx_corpus_storage_info.argtypes = [vp, u64p, u64p, u64p, u64p]
     lib.vfsx_search.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_int, u64p, f32p, u32p]
     lib.vfsx_search_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp]

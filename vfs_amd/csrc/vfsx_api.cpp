@@ -307,6 +307,15 @@ struct vfsx_corpus {
     uint32_t i8_wide = 3;      // VFSX_I8_WIDE: 16-wave int8 scan workgroups per CU (0 = off, 1, 2; 3 = by corpus size)
     uint32_t n_cus = 0;
 
+    // small appends batched on the host (vfsx_corpus_set_insert_batch; off by default): single-row inserts cost a
+    // memcpy, the rows reach the device together -- when `insert_batch` of them wait, or before anything reads the store
+    uint32_t insert_batch = 0;
+    uint64_t pend_n = 0;
+    int pend_mode = 0;
+    bool pend_has_ids = false;
+    std::vector<uint8_t> pend_rows;
+    std::vector<uint64_t> pend_ids;
+
     // host-side metadata of rows loaded from a VFS log (VectorMetadata, vector.rs:11-17), by local row
     using RowMeta = vfsx::RowMeta;
     std::vector<RowMeta> meta; // empty, or one entry per row
@@ -462,7 +471,7 @@ void make_ids_explicit(vfsx_corpus *c)
 }
 
 // mode 0: f32 rows -> f32 corpus, 1: i8 -> i8, 2: f32 -> i8 (quantize on device)
-void append_impl(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n, int mode)
+void append_now(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n, int mode)
 {
     if (n == 0)
         return;
@@ -515,6 +524,49 @@ void append_impl(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t
         c->max_id = new_max;
     }
     c->n_rows += n;
+}
+
+// rows staged by small appends -> the device, in one append (order kept: everything that appends or reads comes here first)
+void commit_pending(vfsx_corpus *c)
+{
+    if (!c->pend_n)
+        return;
+    const uint64_t n = c->pend_n;
+    c->pend_n = 0; // (a failing commit drops the staged rows: the error is the caller's, as a failing append's was)
+    std::vector<uint8_t> rows;
+    std::vector<uint64_t> ids;
+    rows.swap(c->pend_rows);
+    ids.swap(c->pend_ids);
+    append_now(c, rows.data(), c->pend_has_ids ? ids.data() : nullptr, n, c->pend_mode);
+    rows.clear();
+    ids.clear();
+    c->pend_rows.swap(rows); // keep the capacity
+    c->pend_ids.swap(ids);
+}
+
+constexpr uint64_t kSmallAppendRows = 16; // appends up to this many rows are staged when batching is on
+
+void append_impl(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n, int mode)
+{
+    if (c->insert_batch && n && n <= kSmallAppendRows && rows) {
+        if (c->n_rows + c->pend_n + n > 0xfffffffeull - 64u)
+            fail(VFSX_ERR_MEMTABLE, "corpus shard limited to 2^32-66 rows per device");
+        if (c->pend_n && (mode != c->pend_mode || (ids != nullptr) != c->pend_has_ids))
+            commit_pending(c);
+        const size_t row_bytes = (size_t)c->dim * (mode == 1 ? 1u : 4u);
+        const uint8_t *src = (const uint8_t *)rows;
+        c->pend_rows.insert(c->pend_rows.end(), src, src + n * row_bytes);
+        if (ids)
+            c->pend_ids.insert(c->pend_ids.end(), ids, ids + n);
+        c->pend_mode = mode;
+        c->pend_has_ids = ids != nullptr;
+        c->pend_n += n;
+        if (c->pend_n >= c->insert_batch)
+            commit_pending(c);
+        return;
+    }
+    commit_pending(c);
+    append_now(c, rows, ids, n, mode);
 }
 
 bool is_cosine(int metric) { return metric == VFSX_COSINE || metric == VFSX_SIMD_COSINE; }
@@ -1179,6 +1231,14 @@ vfsx_corpus *checked(vfsx_corpus *c)
     return c;
 }
 
+// checked + whatever small appends staged: every entry point that reads the store starts here
+vfsx_corpus *ready(vfsx_corpus *c)
+{
+    checked(c);
+    commit_pending(c);
+    return c;
+}
+
 void fetch_rows(vfsx_corpus *c, const uint64_t *rows, uint64_t n, int as_f32, void *out)
 {
     if (n == 0)
@@ -1370,7 +1430,22 @@ int vfsx_corpus_append_quantize(vfsx_corpus *c, const float *rows, const uint64_
     });
 }
 
-uint64_t vfsx_corpus_rows(const vfsx_corpus *c) { return c ? c->n_rows : 0; }
+uint64_t vfsx_corpus_rows(const vfsx_corpus *c) { return c ? c->n_rows + c->pend_n : 0; }
+int vfsx_corpus_set_insert_batch(vfsx_corpus *c, uint32_t max_pending_rows)
+{
+    return guarded([&] {
+        checked(c);
+        c->insert_batch = max_pending_rows;
+        if (max_pending_rows == 0)
+            commit_pending(c);
+    });
+}
+
+int vfsx_corpus_commit(vfsx_corpus *c)
+{
+    return guarded([&] { ready(c); });
+}
+
 uint32_t vfsx_corpus_dim(const vfsx_corpus *c) { return c ? c->dim : 0; }
 int vfsx_corpus_dtype(const vfsx_corpus *c) { return c ? c->dtype : -1; }
 
@@ -1384,18 +1459,18 @@ int vfsx_corpus_set_row_base(vfsx_corpus *c, uint64_t row_base)
 
 int vfsx_corpus_get_rows_f32(vfsx_corpus *c, const uint64_t *rows, uint64_t n, float *out)
 {
-    return guarded([&] { fetch_rows(checked(c), rows, n, 1, out); });
+    return guarded([&] { fetch_rows(ready(c), rows, n, 1, out); });
 }
 
 int vfsx_corpus_get_rows_raw(vfsx_corpus *c, const uint64_t *rows, uint64_t n, void *out)
 {
-    return guarded([&] { fetch_rows(checked(c), rows, n, 0, out); });
+    return guarded([&] { fetch_rows(ready(c), rows, n, 0, out); });
 }
 
 int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64_t *out)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         if (n && (!rows || !out))
             fail(VFSX_ERR_INVALID_VECTOR, "null buffer");
         for (uint64_t i = 0; i < n; ++i) {
@@ -1409,7 +1484,7 @@ int vfsx_corpus_get_ids(vfsx_corpus *c, const uint64_t *rows, uint64_t n, uint64
 int vfsx_corpus_fill_synthetic(vfsx_corpus *c, uint64_t seed, uint64_t row0, uint64_t n, uint64_t id0)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         // an empty corpus, or one that holds implicit ids which id0 continues (appending in pieces: the growth tests)
         if (c->n_rows != 0 && (c->explicit_ids || id0 != c->id_base + c->n_rows))
             fail(VFSX_ERR_MEMTABLE, "fill_synthetic needs an empty corpus, or ids that continue the implicit run");
@@ -1437,7 +1512,7 @@ int vfsx_corpus_storage_info(vfsx_corpus *c, uint64_t *capacity_rows, uint64_t *
                              uint64_t *device_bytes)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         const VmArray *all[] = {&c->va_corpus, &c->va_norms, &c->va_ids, &c->va_mirror, &c->va_rn2, &c->va_inv};
         uint64_t copied = 0, bytes = 0;
         for (const VmArray *a : all) {
@@ -1459,7 +1534,7 @@ int vfsx_search(vfsx_corpus *c, const float *queries, uint32_t nq, uint32_t k, i
                 float *out_dist, uint32_t *out_count)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         if (nq == 0)
             return;
         if (!queries || !out_ids || !out_dist || !out_count)
@@ -1493,7 +1568,7 @@ int vfsx_search(vfsx_corpus *c, const float *queries, uint32_t nq, uint32_t k, i
 int vfsx_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
                        vfsx_hit *d_hits, void *stream)
 {
-    return guarded([&] { search_device_impl(checked(c), d_queries, nq, k, metric, d_hits, (hipStream_t)stream); });
+    return guarded([&] { search_device_impl(ready(c), d_queries, nq, k, metric, d_hits, (hipStream_t)stream); });
 }
 
 int vfsx_search_device_noalloc(vfsx_corpus *c, const float *d_queries, uint32_t nq, uint32_t k, int metric,
@@ -1501,6 +1576,9 @@ int vfsx_search_device_noalloc(vfsx_corpus *c, const float *d_queries, uint32_t 
 {
     return guarded([&] {
         checked(c);
+        if (c->pend_n) // committing them copies, launches and may map memory: not in the call that allocates nothing
+            fail(VFSX_ERR_MEMTABLE, "vfsx_search_device_noalloc: " + std::to_string(c->pend_n) +
+                                        " appended row(s) wait in the insert batch; call vfsx_corpus_commit first");
         ScanWorkspace ws{};
         unsigned char *base = (unsigned char *)scratch_for_device(c->device);
         ws.lists = (uint64_t *)base;
@@ -1530,7 +1608,7 @@ int vfsx_merge_hits_device(const vfsx_hit *d_in, uint32_t n_lists, uint32_t nq, 
 int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         use_device(c);
         if (enable < 0 || enable > 3)
             fail(VFSX_ERR_INVALID_VECTOR, "vfsx_corpus_enable_mfma: enable must be 0 (off), 1 (auto), 2 (bf16 mirror) or 3 (int8 mirror)");
@@ -1634,7 +1712,7 @@ int vfsx_corpus_load_log_range(vfsx_corpus *c, const char *path, uint64_t first_
                                uint64_t *n_loaded)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         if (!path)
             fail(VFSX_ERR_INVALID_VECTOR, "null path");
         MappedFile f(path);
@@ -1691,7 +1769,7 @@ int vfsx_corpus_load_log_range(vfsx_corpus *c, const char *path, uint64_t first_
 int vfsx_corpus_get_metadata_json(vfsx_corpus *c, uint64_t row, char *buf, uint64_t cap, uint64_t *needed)
 {
     return guarded([&] {
-        checked(c);
+        ready(c);
         if (row >= c->n_rows)
             fail(VFSX_ERR_INVALID_VECTOR, "row index out of range");
         std::string s = "{\"name\":";

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -245,6 +246,20 @@ int vfsx_log_inspect(const char *path, vfsx_log_info *info)
             vfsx::fail(VFSX_ERR_INVALID_VECTOR, "null argument");
         vfsx::MappedFile f(path);
         vfsx::inspect_log_bytes(f.p, f.n, info);
+    });
+}
+
+int vfsx_quantize_rows_host(const float *values, uint64_t n, float scale, int8_t *out)
+{
+    return vfsx::guarded([&] {
+        if (n && (!values || !out))
+            vfsx::fail(VFSX_ERR_INVALID_VECTOR, "null buffer");
+        for (uint64_t i = 0; i < n; ++i) {
+            // Vector::quantize(Some(scale)) (vector.rs:94-108): (v * scale).round() as i8 -- one f32 multiply, round
+            // half away from zero, Rust's saturating float -> int cast (NaN -> 0)
+            const float r = std::round(values[i] * scale);
+            out[i] = r != r ? (int8_t)0 : (r >= 127.0f ? (int8_t)127 : (r <= -128.0f ? (int8_t)-128 : (int8_t)r));
+        }
     });
 }
 

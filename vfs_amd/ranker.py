@@ -143,6 +143,14 @@ class Corpus:
     def fill_synthetic(self, seed: int, n: int, row0: int = 0, id0: int = 1) -> None:
         _lib.check(self._lib.vfsx_corpus_fill_synthetic(self._h, seed, row0, n, id0))
 
+    def set_insert_batch(self, max_pending_rows: int) -> None:
+        """Stage appends of <= 16 rows on the host and commit them together (vfsx_corpus_set_insert_batch): they stay
+        searchable at once -- every read of the store commits first."""
+        _lib.check(self._lib.vfsx_corpus_set_insert_batch(self._h, int(max_pending_rows)))
+
+    def commit(self) -> None:
+        _lib.check(self._lib.vfsx_corpus_commit(self._h))
+
     def storage_info(self) -> dict:
         """Rows backed by memory, slabs behind the row data (0 = one block grown by copy), bytes copied by growth,
         device bytes mapped (vfsx_corpus_storage_info)."""

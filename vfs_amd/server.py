@@ -22,6 +22,7 @@ Deliberate deviations (documented in DESIGN.md)
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import math
 import os
@@ -31,6 +32,8 @@ import time
 from typing import Optional, Tuple
 
 import numpy as np
+
+from . import _lib
 
 STATUS_TEXT = {200: "200 OK", 201: "201 Created", 204: "204 No Content", 400: "400 Bad Request",
                404: "404 Not Found", 500: "500 Internal Server Error"}  # tcp.rs:169-179
@@ -124,6 +127,7 @@ def _new_corpus(dim: int, quantize: bool, device: int):
     return corpus
 
 FLUSH_THRESHOLD = 10  # storage_manager.rs:12
+INSERT_BATCH = 4096   # one-row appends staged on the host before they are committed to the device together
 
 
 class ServerState:
@@ -133,6 +137,8 @@ class ServerState:
         self.quantize = quantize
         self.name = name
         self.corpus = _new_corpus(dim, quantize, device)
+        self.corpus.set_insert_batch(INSERT_BATCH)
+        self._rows = 0                        # rows registered (local row of the next one)
         self.next_id = 1                      # storage_manager.rs:76
         self.row_of = {}                      # id -> local row
         self.meta = {}                        # id -> (name, tags) as the store holds them
@@ -143,20 +149,35 @@ class ServerState:
         self.data_path = os.path.join(data_dir, "vectors.dat")       # storage_manager.rs:13
 
     def register(self, values, name: str, tags) -> int:
+        """register_vector_from_vec (storage_manager.rs:317-335): id = next_id++, into the memtable, flushed to the
+        log at 10.  The vector goes to the engine at once through a one-row append that the library batches on the
+        host (vfsx_corpus_set_insert_batch): it is searchable when this returns, the device work (H2D, rb64 layout /
+        quantize, norm) happens once per batch -- at the next search, or at the flush below for a quantizing store,
+        whose log records hold the stored int8 form."""
         from . import vfslog
         vid = self.next_id
         self.next_id += 1
-        row = len(self.corpus)
-        self.corpus.append_f32(np.asarray(values, dtype=np.float32)[None, :], ids=[vid])
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        row = self._rows
+        self._append(self.corpus.handle, v.ctypes.data, C.byref(C.c_uint64(vid)), 1)
+        self._rows = row + 1
         self.row_of[vid] = row
         if self.quantize:  # Vector::quantize renames and tags the stored form (vector.rs:116-121)
             self.meta[vid] = (name + "_quantized", list(tags) + ["quantized"])
+            self.memtable.append((vid, None, v))
         else:
             self.meta[vid] = (name, list(tags))
-        self.memtable.append((vid, vfslog.utc_now_rfc3339()))
+            self.memtable.append((vid, vfslog.utc_now_rfc3339(), v))
         if len(self.memtable) >= FLUSH_THRESHOLD:  # storage_manager.rs:310-312
             self.flush()
         return vid
+
+    def _append(self, handle, data_ptr, id_ref, n) -> None:
+        lib = self.corpus._lib
+        fn = lib.vfsx_corpus_append_quantize if self.quantize else lib.vfsx_corpus_append
+        rc = fn(handle, C.cast(data_ptr, C.POINTER(C.c_float)) if self.quantize else C.c_void_p(data_ptr), id_ref, n)
+        if rc != _lib.OK:
+            _lib.check(rc)
 
     def flush(self) -> None:
         """flush_memtable_to_disk (storage_manager.rs:139-157): append the pending vectors to the log in
@@ -165,23 +186,31 @@ class ServerState:
         from . import vfslog
         if not self.memtable:
             return
-        rows = [self.row_of[vid] for vid, _ in self.memtable]
-        values = self.corpus.get_rows_raw(rows)
         recs = []
-        for (vid, created), v in zip(self.memtable, values):
-            name, tags = self.meta[vid]
-            if self.quantize:  # quantize() stamps a fresh created_at (vector.rs:122)
-                recs.append(vfslog.encode_record(vid, v, name, tags, vfslog.utc_now_rfc3339(), scale=127.0))
-            else:
+        if self.quantize:  # quantize() stamps a fresh created_at (vector.rs:122)
+            # the stored int8 form, by the store's own rule on the host (vfsx_quantize_rows_host = the bytes the device
+            # quantizer left in HBM: no read-back, no commit of the rows still staged in the insert batch)
+            f32 = np.ascontiguousarray(np.stack([v for _, _, v in self.memtable]), dtype=np.float32)
+            values = np.empty(f32.shape, dtype=np.int8)
+            _lib.check(self.corpus._lib.vfsx_quantize_rows_host(
+                f32.ctypes.data_as(C.POINTER(C.c_float)), f32.size, 127.0, values.ctypes.data_as(C.POINTER(C.c_int8))))
+            now = vfslog.utc_now_rfc3339()
+            for (vid, _, _), v in zip(self.memtable, values):
+                name, tags = self.meta[vid]
+                recs.append(vfslog.encode_record(vid, v, name, tags, now, scale=127.0))
+        else:
+            for vid, created, v in self.memtable:
+                name, tags = self.meta[vid]
                 recs.append(vfslog.encode_record(vid, v, name, tags, created))
         offsets = vfslog.append_records(self.data_path, recs)
-        for (vid, _), off in zip(self.memtable, offsets):
+        for (vid, _, _), off in zip(self.memtable, offsets):
             self.index_map[vid] = off
         self.memtable = []
 
     def load_log(self, path: str) -> int:
         row0 = len(self.corpus)
         n = self.corpus.load_log(path)
+        self._rows = row0 + n
         ids = self.corpus.get_ids(np.arange(row0, row0 + n))
         for i, vid in enumerate(ids):
             self.row_of[int(vid)] = row0 + i
