@@ -301,13 +301,32 @@ __global__ __launch_bounds__(64 * kWideWaves) void scan_i8w_kernel(
         top.offer_dense(comp);
     };
 
+    // Whole rounds: wave w of workgroup b takes row-block round * n_waves + 16 b + w, so a workgroup reads 16
+    // adjacent row-blocks at a time (measured: wave-major strides through the corpus cost 10 % at C3).  The
+    // n_rowblocks % n_waves row-blocks of the last, partial round go wave-major instead -- to wave 0 (1, ...) of
+    // EVERY workgroup rather than to all 16 waves of the first few: the kernel is VALU-bound, a CU is done when
+    // its slowest workgroup is, and this way no workgroup carries 16 extra row-blocks.
+    const uint32_t n_whole = (n_rowblocks / n_waves) * n_waves;
+#ifdef VFSX_EXP_I8W_BLOCKMAJOR
+    const uint32_t tail = n_whole + blockIdx.x * kWideWaves + wave;
+#else
+    const uint32_t tail = n_whole + wave * gridDim.x + blockIdx.x;
+#endif
     uint32_t blk = blockIdx.x * kWideWaves + wave;
-    if (METRIC == VFSX_COSINE && blk < n_rowblocks) { // first row-block also folds sum q_j^2
+    bool have_qn = METRIC != VFSX_COSINE;
+    if (METRIC == VFSX_COSINE && blk < n_whole) { // first row-block also folds sum q_j^2
         rowblock(blk, std::true_type{});
         blk += n_waves;
+        have_qn = true;
     }
-    for (; blk < n_rowblocks; blk += n_waves)
+    for (; blk < n_whole; blk += n_waves)
         rowblock(blk, std::false_type{});
+    if (tail < n_rowblocks) {
+        if (have_qn)
+            rowblock(tail, std::false_type{});
+        else
+            rowblock(tail, std::true_type{});
+    }
 
     // fold the 16 waves' lists into wave 0's, one list per workgroup to HBM ([q][j][list]); the
     // table is dead once every wave has left the scan, its LDS holds the 16 lists
