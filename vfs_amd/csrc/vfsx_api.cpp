@@ -939,7 +939,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     use_device(c);
     ensure_mirror(c, s);
     const bool i8 = prefilter_is_i8(c);
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8, nq <= 128u ? c->n_cus : 0u);
     const size_t qm_elem = i8 ? 1u : 2u; // query mirror: int8 or bf16
     // the int8 prefilter's row operand: the int8 store itself, or the int8 mirror of an f32 store
     const uint4 *a_rows = mirror_is_i8(c) ? c->d_mirror : c->d_corpus;

@@ -121,7 +121,9 @@ struct MfmaGeometry {
 };
 constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor assumes K <= 32768
 constexpr uint32_t kMfmaMaxK = 128; // result_limit the matrix-core batch path serves (256 candidates re-scored per query)
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8);
+// skinny_cus != 0: the call takes <= 128 queries (one workgroup per strip and CU) on a device with that many CUs --
+// the strip length is then chosen for whole rounds of workgroups
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t skinny_cus = 0);
 float mfma_f32_slack(uint32_t k_pad);
 
 struct MfmaRescoreArgs {

@@ -2322,7 +2322,7 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     return hipGetLastError();
 }
 
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8)
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t skinny_cus)
 {
     MfmaGeometry g;
     // whole ring rounds only: K-steps (of 4 MFMA k-slices: 64 bf16 / 128 int8 k) per tile % ring depth (2) == 0, i.e.
@@ -2336,6 +2336,29 @@ MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8)
     // one (small corpora get short strips -- and more workgroups); a list holds at most 1024 rows (10 index
     // bits): at most 16 tiles = 4096 rows per strip, 4 lists per strip
     g.strip_tiles = std::min<uint32_t>(kMaxStripTiles, std::max<uint32_t>(1u, (n_rows / 256u) * 4u / 4096u));
+    if (skinny_cus) {
+        // <= 128 queries (mfma_prefilter_skinny_kernel): one workgroup per strip and ONE workgroup per CU (its ring
+        // is 120 KiB), all strips the same length -- the launch takes ceil(strips / CUs) rounds of (strip_tiles tiles
+        // + about half a tile of ring fill and epilogue).  C2 (3907 tiles): 3 tiles per strip = 1303 workgroups =
+        // 5.09 -> 6 rounds = 18 tile times for 15.26 tiles of work per CU; 4 per strip = 3.82 -> 4 rounds = 16
+        // (measured 0.143 -> 0.128 ms, profiles/r03/c2m_strip_sweep.txt).  Pick the cheapest strip length that still
+        // leaves >= 2048 lists per query (the safety check flags a list with three rows above the margin: its
+        // rate grows with 1 / lists^2); ties go to the shorter strip.
+        uint32_t best = g.strip_tiles;
+        uint64_t best_cost = ~0ull;
+        for (uint32_t st = 1; st <= kMaxStripTiles; ++st) {
+            const uint32_t strips = (g.n_rowtiles + st - 1u) / st;
+            if (strips * 4u < 2048u && st > 1u)
+                break;
+            const uint64_t cost = (uint64_t)((strips + skinny_cus - 1u) / skinny_cus) * (2u * st + 1u);
+            if (cost < best_cost)
+                best_cost = cost, best = st;
+        }
+        g.strip_tiles = best;
+    }
+    static const uint32_t forced = std::getenv("VFSX_MFMA_STRIP") ? (uint32_t)std::atoi(std::getenv("VFSX_MFMA_STRIP")) : 0u;
+    if (forced >= 1u && forced <= kMaxStripTiles) // experiments
+        g.strip_tiles = forced;
     g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
     g.n_lists = g.n_strips * 4u;
     g.mirror_bytes = int8 ? 0 : (size_t)g.n_rowtiles * 256u * g.k_pad * 2u; // int8 stores need no mirror
