@@ -39,7 +39,7 @@ bench = json.loads(bench_line)
 out = {"bench_line_under_profiler": bench, "kernels": []}
 md = [f"# rocprofv3 summary `{tag}` ({rnd})", "",
       "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline "
-      f"--workload {tag}` (steps/warmup as in tools/r02_profiles.sh); PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (one run each).",
+      f"--workload {tag}` (steps/warmup as in tools/{rnd}_profiles.sh); PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (one run each).",
       "", "| kernel | calls | avg µs | % time | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM bytes/launch (2·fetch+write) |",
       "|---|---|---|---|---|---|---|"]
 for r in rows:
