@@ -157,7 +157,9 @@ int vfsx_corpus_append_quantize(vfsx_corpus *c, const float *rows, const uint64_
  * layout / quantize launch, one norm launch for the lot -- as soon as max_pending_rows of them wait, and before
  * ANYTHING reads the store (every search, get_rows / get_ids, larger appends, log loads, enable_mfma ...): a vector
  * is searchable the moment its append returns, exactly once (the reference shows memtable vectors twice).
- * An error of the deferred device work (out of memory) is reported by the call that commits and drops the staged rows.
+ * An error of the deferred device work (out of memory) is reported by the call that commits; the rows stay staged (their
+ * appends returned success: nothing is dropped silently) and every later call that must commit reports the error again
+ * until a commit goes through or the corpus is destroyed.
  * vfsx_corpus_rows counts staged rows.  vfsx_search_device_noalloc never commits: with rows staged it fails with
  * VFSX_ERR_MEMTABLE -- call vfsx_corpus_commit first.  0 switches batching off and commits.
  */

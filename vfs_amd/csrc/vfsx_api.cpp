@@ -85,8 +85,8 @@ struct DeviceBuf {
 // The corpus, its norms and ids (and the int8 operands of the batch path) grow without ever moving a stored row:
 // one contiguous VIRTUAL range per array is reserved up front (hipMemAddressReserve: address space, no memory) and
 // physical slabs are created and mapped behind the part already in use as the store grows (hipMemCreate /
-// hipMemMap / hipMemSetAccess) -- first a slab of the declared capacity, then slabs that double the array up to
-// kSlabBytes each, then one kSlabBytes slab at a time.  The kernels keep seeing ONE base pointer and the rb64
+// hipMemMap / hipMemSetAccess) -- slabs of ONE size per array, a power of two between min_slab and kSlabBytes fixed
+// by the first request (see `slab` below for why).  The kernels keep seeing ONE base pointer and the rb64
 // indexing they always had (no slab table, no per-access indirection), growth costs a map call instead of
 // "allocate twice the size and copy" -- which capped a store that was not sized up front at a third of the
 // card (old block + new block live together) -- and device pointers handed out earlier (a captured HIP graph)
@@ -531,17 +531,13 @@ void commit_pending(vfsx_corpus *c)
 {
     if (!c->pend_n)
         return;
-    const uint64_t n = c->pend_n;
-    c->pend_n = 0; // (a failing commit drops the staged rows: the error is the caller's, as a failing append's was)
-    std::vector<uint8_t> rows;
-    std::vector<uint64_t> ids;
-    rows.swap(c->pend_rows);
-    ids.swap(c->pend_ids);
-    append_now(c, rows.data(), c->pend_has_ids ? ids.data() : nullptr, n, c->pend_mode);
-    rows.clear();
-    ids.clear();
-    c->pend_rows.swap(rows); // keep the capacity
-    c->pend_ids.swap(ids);
+    // append_now leaves the corpus as it was when it fails; the rows then STAY staged -- their appends have returned
+    // success, so they are not dropped behind the caller's back: the call that needed the commit reports the error,
+    // and so does every later one until a commit goes through (or the corpus is destroyed)
+    append_now(c, c->pend_rows.data(), c->pend_has_ids ? c->pend_ids.data() : nullptr, c->pend_n, c->pend_mode);
+    c->pend_n = 0;
+    c->pend_rows.clear(); // (keeps the capacity)
+    c->pend_ids.clear();
 }
 
 constexpr uint64_t kSmallAppendRows = 16; // appends up to this many rows are staged when batching is on
