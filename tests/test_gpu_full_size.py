@@ -246,3 +246,50 @@ def test_c5_shard_12m5_x768_euclidean_properties(oracle):
     ids100, dist100, _ = c.search_batch(q, 100, 2)
     assert (ids100[0, :10] == ids[0]).all() and (bits(dist100[0, :10]) == bits(dist[0])).all()
     c.close()
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_shard_row_limit_4_29e9_rows(oracle, quantize):
+    """Maximum size of one shard: 2^32 - 66 rows (the row index travels in 32 bits of the composite key).  16 bytes
+    per row (d = 4 f32 / d = 16 int8) = 68.7 GB filled on the device; queries that ARE stored rows (first, middle,
+    last row-block, last row) must come back first at distance 0 with the right 33-bit-range id, every hit's distance
+    must equal the oracle's on the row read back, no sampled row may beat the 10th hit, and one row more is refused."""
+    import vfs_amd
+    limit = (1 << 32) - 66
+    d = 16 if quantize else 4
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    done = 0
+    while done < limit:
+        n = min(1 << 30, limit - done)
+        c.fill_synthetic(7, n, row0=done, id0=done + 1)
+        done += n
+    assert len(c) == limit
+    info = c.storage_info()
+    assert info["capacity_rows"] == (1 << 32) - 64 and info["copied_bytes"] == 0
+    kw = {"scale": 127.0} if quantize else {}
+    for metric in (0, 1):
+        for r in (0, 1 << 31, limit - 65, limit - 1):
+            q = c.get_rows_f32(np.array([r], np.uint64))[0]
+            ids, dist, cnt = c.search_batch(q[None, :], 10, metric)
+            assert int(cnt[0]) == 10
+            back = c.get_rows_raw((ids[0] - 1).astype(np.uint64))
+            oi, od, _ = oracle.topk_scan(back, q, metric, 10, ids=ids[0].astype(np.uint64), **kw)
+            assert (oi == ids[0]).all() and (bits(od) == bits(dist[0])).all(), (metric, r, ids, dist, od)
+            if metric == 0:
+                # (int8: another row may quantize to the same bytes -- then the earlier one wins the tie)
+                assert dist[0][0] == 0.0 and (int(ids[0][0]) == r + 1 or quantize), (r, ids[0][:3], dist[0][:3])
+            assert (r + 1) in ids[0].tolist() or quantize, (r, ids[0], dist[0])
+    rng = np.random.default_rng(0)
+    sample = rng.integers(0, limit, 200_000).astype(np.uint64)
+    q = c.get_rows_f32(np.array([limit - 1], np.uint64))[0]
+    ids, dist, cnt = c.search_batch(q[None, :], 10, 0)
+    _, od, _ = oracle.topk_scan(c.get_rows_raw(sample), q, 0, 1, **kw)
+    assert od[0] >= dist[0][9] or (sample + 1 == ids[0][:, None]).any(), (od, dist)
+    with pytest.raises(vfs_amd.VfsxError) as e:
+        c.fill_synthetic(7, 1, row0=limit, id0=limit + 1)
+    assert "2^32-66" in str(e.value)
+    c.enable_mfma(True)  # beyond the matrix-core path's row range: stays on the exact scan, same hits
+    im, dm, _ = c.search_batch(np.repeat(q[None, :], 4, axis=0), 10, 0)
+    assert (im[3] == ids[0]).all() and (bits(dm[3]) == bits(dist[0])).all()
+    assert c.mfma_stats()[0] == 0
+    c.close()

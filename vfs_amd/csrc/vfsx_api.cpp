@@ -379,19 +379,23 @@ void use_device(const vfsx_corpus *c) { HIP_CHECK(hipSetDevice(c->device)); }
 
 uint64_t round_up64(uint64_t x) { return (x + 63u) / 64u * 64u; }
 
+// a shard holds at most 2^32 - 66 rows (the row index travels in 32 bits of the composite key, the top values are
+// sentinels); its capacity, a whole number of 64-row blocks, therefore at most 2^32 - 64
+constexpr uint64_t kMaxCapacityRows = 0xffffffc0ull;
+
 void reserve_rows(vfsx_corpus *c, uint64_t want_rows)
 {
+    if (want_rows > 0xfffffffeull - 64u) // (before the capacity check: the last row-block has room for two rows more)
+        fail(VFSX_ERR_MEMTABLE, "corpus shard limited to 2^32-66 rows per device");
     if (want_rows <= c->capacity)
         return;
-    if (want_rows > 0xfffffffeull - 64u)
-        fail(VFSX_ERR_MEMTABLE, "corpus shard limited to 2^32-66 rows per device");
     if (c->va_corpus.reserved && want_rows > c->max_rows)
         fail(VFSX_ERR_MEMTABLE, "corpus of " + std::to_string(want_rows) + " rows exceeds the device's memory");
     const uint64_t rows = std::max<uint64_t>(round_up64(want_rows), 64);
     const size_t used_rows = (size_t)round_up64(c->n_rows);
     // the corpus grows first; the rows its mapped bytes hold become the capacity the side arrays follow
     c->va_corpus.grow(c->corpus_bytes(rows), c->corpus_bytes(used_rows), c->stream);
-    uint64_t cap = std::min<uint64_t>(c->va_corpus.mapped / c->block_bytes() * 64u, 0xffffff00ull);
+    uint64_t cap = std::min<uint64_t>(c->va_corpus.mapped / c->block_bytes() * 64u, kMaxCapacityRows);
     if (c->va_corpus.reserved)
         cap = std::min<uint64_t>(cap, c->max_rows);
     const size_t norms_before = c->va_norms.mapped;
@@ -1162,7 +1166,7 @@ void search_device_impl(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     // the reference's four metrics; the integer-domain extension has its own kernel
     const bool metric_ok = metric != VFSX_EUCLIDEAN_I8DOMAIN;
     const bool mfma_ok = c->mfma_enabled && metric_ok && nq >= mfma_min_batch_for(c, k) && k <= vfsx::kMfmaMaxK && c->dim <= vfsx::kMfmaMaxDim &&
-                         c->n_rows >= 16384 && !(c->mirror_rows == c->n_rows && c->mirror_bad);
+                         c->n_rows >= 16384 && c->n_rows <= vfsx::kMfmaMaxRows && !(c->mirror_rows == c->n_rows && c->mirror_bad);
     if (mfma_ok && c->mfma_backoff > 0) {
         --c->mfma_backoff; // see vfsx_corpus::mfma_backoff
         exact_search_device(c, d_queries, nq, k, metric, d_hits, s);
@@ -1332,7 +1336,7 @@ vfsx_corpus *vfsx_corpus_create(uint32_t dim, int dtype, float scale, uint64_t c
         // address ranges for the arrays that grow with the store: as many rows as the device's memory could hold
         {
             const uint64_t by_mem = std::max<uint64_t>(64, (uint64_t)prop.totalGlobalMem / c->block_bytes() * 64u);
-            c->max_rows = std::min<uint64_t>(by_mem, 0xffffff00ull);
+            c->max_rows = std::min<uint64_t>(by_mem, kMaxCapacityRows);
             c->va_corpus.min_slab = 64u << 20; // row data: 64 MiB .. 1 GiB per slab; side arrays: 2 MiB .. 1 GiB
             c->va_corpus.init(device, c->corpus_bytes(c->max_rows));
             if (c->va_corpus.reserved) {
@@ -1631,7 +1635,7 @@ int vfsx_corpus_enable_mfma(vfsx_corpus *c, int enable)
             c->mirror_rows = 0;
             c->mirror_bytes = 0;
         }
-        if (c->n_rows)
+        if (c->n_rows && c->n_rows <= vfsx::kMfmaMaxRows)
             ensure_mirror(c, c->stream);
     });
 }

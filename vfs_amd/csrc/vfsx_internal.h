@@ -120,6 +120,9 @@ struct MfmaGeometry {
     size_t mirror_bytes; // bf16 mirror of the corpus (rows padded to 256); 0 for int8 stores (rb64 is the operand)
 };
 constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor assumes K <= 32768
+// rows the matrix-core path takes: its kernels pad the row count to 256-row tiles in 32-bit arithmetic (larger shards,
+// up to the 2^32 - 66 the exact scan serves, keep the exact scan)
+constexpr uint64_t kMfmaMaxRows = 0xfffffe00ull;
 constexpr uint32_t kMfmaMaxK = 128; // result_limit the matrix-core batch path serves (256 candidates re-scored per query)
 // skinny_cus != 0: the call takes <= 128 queries (one workgroup per strip and CU) on a device with that many CUs --
 // the strip length is then chosen for whole rounds of workgroups
