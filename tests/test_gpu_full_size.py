@@ -293,3 +293,24 @@ def test_shard_row_limit_4_29e9_rows(oracle, quantize):
     assert (im[3] == ids[0]).all() and (bits(dm[3]) == bits(dist[0])).all()
     assert c.mfma_stats()[0] == 0
     c.close()
+
+
+def test_result_limit_at_the_maximum(oracle):
+    """VFSX_MAX_K = 2^20 hits from one call (the reference's result_limit is unbounded, rank.rs:129,172-173):
+    1.3M rows with duplicates, the whole ranking equal to the oracle's stable sort, ids and distance bits."""
+    import vfs_amd
+    n, d, k = 1_300_000, 8, 1 << 20
+    rows = oracle.synth_f32(SEED_C, 0, n, d)
+    rows[500_000:500_300] = rows[7]  # 300 exact ties far from their first occurrence
+    q = oracle.synth_f32(SEED_Q, 0, 1, d)[0]
+    c = vfs_amd.Corpus(d, capacity_rows=n)
+    c.append(rows)
+    for metric in (0, 1):
+        ids, dist, cnt = c.search_batch(q[None, :], k, metric)
+        # the oracle's bounded insertion is O(n k): at this k rank its per-row distances with a stable sort instead
+        # (rank.rs:170 is a stable sort by distance: ties keep scan order)
+        alld = oracle.all_distances(rows, q, metric)
+        order = np.argsort(alld, kind="stable")[:k]
+        assert int(cnt[0]) == k
+        assert (ids[0] == order.astype(np.uint64) + 1).all() and (bits(dist[0]) == bits(alld[order])).all(), metric
+    c.close()
