@@ -246,3 +246,30 @@ def test_select_bound_with_more_lists_than_the_select_has_waves(oracle, monkeypa
                 assert cnt[qi] == k and (ids[qi] == oi).all(), (metric, k, qi)
                 assert (dist[qi].view(np.uint32) == od.view(np.uint32)).all(), (metric, k, qi)
     c.close()
+
+
+@pytest.mark.parametrize("d,quantize", [(4099, False), (65536, False), (200_001, False), (70_001, True)])
+def test_very_long_rows(oracle, d, quantize):
+    """Dimensions far beyond the BASELINE shapes (the reference accepts any Vec length): rows of up to 800 KB, ragged
+    against the 16-byte chunk, single queries and a 3-query call (queries longer than the staging LDS take one pass
+    each), every reference method, against the oracle bit for bit."""
+    import vfs_amd
+    rng = np.random.default_rng(d)
+    n = 700 if d > 100_000 else 1500
+    rows = rng.uniform(-1, 1, (n, d)).astype(np.float32)
+    rows[n - 3] = rows[5]  # an exact duplicate: tie by scan order
+    queries = rng.uniform(-1, 1, (3, d)).astype(np.float32)
+    queries[1] = rows[5]
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    (c.append_f32 if quantize else c.append)(rows)
+    ref = oracle.quantize(rows, 127.0) if quantize else rows
+    kw = {"scale": 127.0} if quantize else {}
+    for metric in (0, 1, 2, 3):
+        ids, dist, cnt = c.search_batch(queries, 7, metric)
+        one = c.search_batch(queries[2:3], 7, metric)
+        for qi in range(3):
+            oi, od, _ = oracle.topk_scan(ref, queries[qi], metric, 7, **kw)
+            assert cnt[qi] == 7 and (ids[qi] == oi).all(), (d, metric, qi, ids[qi], oi)
+            assert (_bits(dist[qi]) == _bits(od)).all(), (d, metric, qi)
+        assert (one[0][0] == ids[2]).all() and (_bits(one[1][0]) == _bits(dist[2])).all()
+    c.close()
