@@ -547,3 +547,28 @@ def test_mfma_appends_extend_the_operand(oracle, quantize):
                 assert im[step % len(queries), 0] == total - n_new + 1  # (ids start at 1): the row appended just now
     c.close()
     twin.close()
+
+
+@pytest.mark.parametrize("d,quantize,taken", [(32768, False, True), (32768, True, True), (5000, False, True),
+                                              (32769, False, False)])
+def test_mfma_at_the_largest_dimension(d, quantize, taken):
+    """The matrix-core path serves rows of up to 32 768 dimensions (the error model's bound on K); one more and the
+    call keeps the exact scan.  Small and tile-sized batches against the exact scan of the same store, bit for bit."""
+    import vfs_amd
+    n = 17000
+    c = vfs_amd.Corpus(d, quantize=quantize)
+    c.fill_synthetic(11, n)
+    rng = np.random.default_rng(d + quantize)
+    base = c.get_rows_f32(rng.integers(0, n, 130).astype(np.uint64))
+    queries = (base + rng.normal(0, 0.05, base.shape)).astype(np.float32)
+    for nq in (5, 130):
+        for metric in (1, 0):
+            c.enable_mfma(False)
+            ie, de, ce = c.search_batch(queries[:nq], 10, metric)
+            c.enable_mfma(True)
+            c.mfma_stats(reset=True)
+            im, dm, cm = c.search_batch(queries[:nq], 10, metric)
+            mq, fb = c.mfma_stats()
+            assert (mq == nq) == taken, (d, nq, metric, mq, fb)
+            assert (cm == ce).all() and (im == ie).all() and (bits(dm) == bits(de)).all(), (d, nq, metric)
+    c.close()
