@@ -296,6 +296,7 @@ struct vfsx_corpus {
     DeviceBuf<uint64_t> lists;
     DeviceBuf<float> q_in, q_pad;
     DeviceBuf<vfsx_hit> hits;
+    void *h_call = nullptr, *d_call = nullptr; // vfsx_search's pinned block for small calls (host / device address)
     DeviceBuf<uint64_t> row_idx;
     DeviceBuf<uint8_t> row_out;
     uint32_t max_blocks = 0;
@@ -382,6 +383,7 @@ uint64_t round_up64(uint64_t x) { return (x + 63u) / 64u * 64u; }
 // a shard holds at most 2^32 - 66 rows (the row index travels in 32 bits of the composite key, the top values are
 // sentinels); its capacity, a whole number of 64-row blocks, therefore at most 2^32 - 64
 constexpr uint64_t kMaxCapacityRows = 0xffffffc0ull;
+constexpr size_t kPinnedCallBytes = 256u << 10; // vfsx_search: queries + hits of a call up to this size go through pinned memory
 
 void reserve_rows(vfsx_corpus *c, uint64_t want_rows)
 {
@@ -1400,6 +1402,9 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->q_in.release();
     c->q_pad.release();
     c->hits.release();
+    if (c->h_call)
+        (void)hipHostFree(c->h_call);
+    c->h_call = c->d_call = nullptr;
     c->row_idx.release();
     c->row_out.release();
     c->va_corpus.release();
@@ -1543,13 +1548,33 @@ int vfsx_search(vfsx_corpus *c, const float *queries, uint32_t nq, uint32_t k, i
             fail(VFSX_ERR_INVALID_VECTOR, "k (result_limit) must be in 1.." + std::to_string(VFSX_MAX_K));
         use_device(c);
         c->q_in.reserve((size_t)nq * c->dim);
-        c->hits.reserve((size_t)nq * k);
-        HIP_CHECK(hipMemcpyAsync(c->q_in.p, queries, (size_t)nq * c->dim * sizeof(float), hipMemcpyHostToDevice,
-                                 c->stream));
-        search_device_impl(c, c->q_in.p, nq, k, metric, c->hits.p, c->stream);
-        std::vector<vfsx_hit> h((size_t)nq * k);
-        HIP_CHECK(hipMemcpyAsync(h.data(), c->hits.p, h.size() * sizeof(vfsx_hit), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+        const size_t q_bytes = (size_t)nq * c->dim * sizeof(float), h_bytes = (size_t)nq * k * sizeof(vfsx_hit);
+        std::vector<vfsx_hit> h_big;
+        const vfsx_hit *h = nullptr;
+        if (q_bytes + h_bytes <= kPinnedCallBytes) {
+            // Small calls (a query or a few, tens of hits: what Ranker::search hands over) through ONE pinned block:
+            // the query is copied out of it without HIP's pageable staging, and the kernels write the hits straight
+            // into it (host memory the device can address), so there is no copy back at all -- one stream
+            // synchronisation is the whole host side.  C1 (100k x 128): 36.6 -> see DESIGN 6 "Host buffers".
+            if (!c->h_call) {
+                HIP_CHECK(hipHostMalloc(&c->h_call, kPinnedCallBytes, hipHostMallocDefault));
+                HIP_CHECK(hipHostGetDevicePointer(&c->d_call, c->h_call, 0));
+            }
+            // hits first (24-byte records from offset 0), the queries behind them
+            std::memcpy((char *)c->h_call + h_bytes, queries, q_bytes);
+            HIP_CHECK(hipMemcpyAsync(c->q_in.p, (char *)c->h_call + h_bytes, q_bytes, hipMemcpyHostToDevice, c->stream));
+            search_device_impl(c, c->q_in.p, nq, k, metric, (vfsx_hit *)c->d_call, c->stream);
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            h = (const vfsx_hit *)c->h_call;
+        } else {
+            c->hits.reserve((size_t)nq * k);
+            HIP_CHECK(hipMemcpyAsync(c->q_in.p, queries, q_bytes, hipMemcpyHostToDevice, c->stream));
+            search_device_impl(c, c->q_in.p, nq, k, metric, c->hits.p, c->stream);
+            h_big.resize((size_t)nq * k);
+            HIP_CHECK(hipMemcpyAsync(h_big.data(), c->hits.p, h_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            h = h_big.data();
+        }
         for (uint32_t q = 0; q < nq; ++q) {
             uint32_t cnt = 0;
             for (uint32_t j = 0; j < k; ++j) {
