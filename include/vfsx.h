@@ -116,8 +116,8 @@ const char *vfsx_version(void);
  *                  127.0 (vector.rs:188).  Ignored for VFSX_F32.
  *   capacity_rows  rows to back with memory up front.  The store grows past it without moving a row: the
  *                  row data, norms and ids each live in ONE virtual address range reserved for the device's
- *                  worth of rows, and memory is mapped behind it slab by slab (doubling up to 1 GiB per slab,
- *                  then 1 GiB at a time; HIP virtual memory management) -- an append never copies what is
+ *                  worth of rows, and memory is mapped behind it in equal-size segments (64 MiB to 1 GiB for the
+ *                  row data, fixed by the first growth; HIP virtual memory management) -- an append never copies what is
  *                  stored, a store that was not sized up front can fill the card (round 2 reallocated twice
  *                  the size and copied: a third of the card at most), and device addresses handed out earlier
  *                  stay valid.  The reference's feed is an unbounded append (storage_manager.rs:139-157).
@@ -139,6 +139,10 @@ void vfsx_corpus_destroy(vfsx_corpus *c);
  * `ids` NULL => ids continue 1,2,3.. (storage_manager.rs:76,126-130).
  * Host rows are staged through pinned double buffers and copied with
  * hipMemcpyAsync, then laid out on the device ("HBM layout").
+ * One corpus (= one shard) holds at most 2^32 - 66 rows: the row's scan position travels in 32 bits of the key the
+ * kernels rank by (larger stores are row-sharded, vfsx_corpus_set_row_base).  An append beyond that fails with
+ * VFSX_ERR_MEMTABLE and leaves the corpus as it was.  (The matrix-core batch path serves shards of up to
+ * 2^32 - 512 rows; larger ones keep the exact scan.)
  */
 int vfsx_corpus_append(vfsx_corpus *c, const void *rows, const uint64_t *ids, uint64_t n);
 
