@@ -330,7 +330,7 @@ struct vfsx_corpus {
     float *d_rn2 = nullptr;      // [mirror rows padded] float2 (b, b^2 (1 - gamma)) for Euclidean batches
     float *d_inv_rn = nullptr;   // int8 stores: [same rows] 1 / (scale b); the rb64 corpus is the MFMA operand, no mirror
     size_t rn2_rows = 0;
-    DeviceBuf<float> q_norm, q_eps, q_scale;
+    DeviceBuf<float> q_norm, q_eps, q_scale, q_dk;
     DeviceBuf<uint32_t> long_state, long_hist; // result_limit > kLongResultK: radix-select state / histograms
     DeviceBuf<uint64_t> long_sel;              // ... and the compacted keys of one chunk per query
     DeviceBuf<uint32_t> fb_idx;  // exact fallback of flagged queries: their indices, compacted copies, hits
@@ -941,7 +941,9 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     use_device(c);
     ensure_mirror(c, s);
     const bool i8 = prefilter_is_i8(c);
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8, nq <= 128u ? c->n_cus : 0u);
+    // (query tiles per prefilter launch: a call of more queries than one round holds runs several launches of
+    // q_round; the geometry is the first one's, the others are at least as large)
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8, c->n_cus, (nq + 255u) / 256u);
     const size_t qm_elem = i8 ? 1u : 2u; // query mirror: int8 or bf16
     // the int8 prefilter's row operand: the int8 store itself, or the int8 mirror of an f32 store
     const uint4 *a_rows = mirror_is_i8(c) ? c->d_mirror : c->d_corpus;
@@ -975,6 +977,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     c->q_bad.reserve(nq);
     c->q_norm.reserve(nq);
     c->q_eps.reserve(nq);
+    c->q_dk.reserve(nq);
     if (i8)
         c->q_scale.reserve(nq);
     c->q_flags.reserve(nq);
@@ -1025,13 +1028,20 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.euclid = euclid;
         a.q_norm = c->q_norm.p + q0;
         a.gamma = mfma_gamma(g.k_pad);
+        a.dk_out = c->q_dk.p + q0;
         HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
         // second pass, entirely on the device: a query that failed because more than kp rows sit above its
         // safety margin gets the widest candidate set the re-score kernel takes (256) and is decided
         // again; queries that passed exit at once.  (A list with three entries above the margin stays
         // flagged: only the exact scan can look inside it.)
         if (kp < 256u) {
-            HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, 256u, a.flags, s));
+            static const bool wide_select = std::getenv("VFSX_MFMA_WIDE") && std::getenv("VFSX_MFMA_WIDE")[0] == 's';
+            if (wide_select) // (A/B: round 2's sorted 256-deep select)
+                HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, 256u, a.flags, s));
+            else // every candidate above the first pass' margin, unsorted (mfma_filter_kernel)
+                HIP_CHECK(vfsx::launch_mfma_filter(c->cand.p, c->sel.p, qn, g.n_lists, a.flags, a.q_bad, c->q_dk.p + q0,
+                                                   a.q_eps, a.q_scale, a.q_norm, a.gamma, euclid, s));
+            a.dk_out = nullptr;
             a.kp = 256u;
             a.only_flagged = 1;
             HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
@@ -1388,6 +1398,7 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->q_bad.release();
     c->q_norm.release();
     c->q_eps.release();
+    c->q_dk.release();
     c->q_scale.release();
     c->long_state.release();
     c->long_hist.release();

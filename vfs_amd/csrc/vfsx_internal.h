@@ -124,9 +124,9 @@ constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor a
 // up to the 2^32 - 66 the exact scan serves, keep the exact scan)
 constexpr uint64_t kMfmaMaxRows = 0xfffffe00ull;
 constexpr uint32_t kMfmaMaxK = 128; // result_limit the matrix-core batch path serves (256 candidates re-scored per query)
-// skinny_cus != 0: the call takes <= 128 queries (one workgroup per strip and CU) on a device with that many CUs --
-// the strip length is then chosen for whole rounds of workgroups
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t skinny_cus = 0);
+// n_cus != 0: the geometry of ONE prefilter launch over n_qtiles query tiles (1 for <= 128 queries: the small-batch
+// kernel) on a device with that many CUs -- the strip length is then chosen for whole rounds of workgroups
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_cus = 0, uint32_t n_qtiles = 1);
 float mfma_f32_slack(uint32_t k_pad);
 
 struct MfmaRescoreArgs {
@@ -148,6 +148,7 @@ struct MfmaRescoreArgs {
     float gamma;          // relative f32 error allowance of the Euclidean check
     int only_flagged;     // != 0: second pass, only queries whose flags[q] is set (they are re-decided)
     const float *q_scale; // int8 stores: [nq] s_q, the query's quantization step (nullptr on the bf16 path)
+    float *dk_out;        // [nq] (or nullptr): the k-th exact distance this pass found (NaN: fewer than k hits)
 };
 // stats[2] (device): [0] != 0: a row norm outside the path's range; [1]: R_x, the mirror's largest rounding
 // residual (float bits).  Both zeroed by the caller before the two launches.
@@ -178,6 +179,11 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
                                  const MfmaGeometry &g, uint32_t nq, int euclid, const float *rn2,
                                  const float *q_norm, const float *q_eps, hipStream_t s);
 // only_flagged != nullptr: skip queries whose flag is 0
+// second pass: sel[q][0..256) = every listed candidate of a flagged query whose score reaches the safety margin of the
+// first pass' k-th distance dk1[q] (unsorted; all sentinels when more than 256 do)
+hipError_t launch_mfma_filter(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, const int *flags,
+                              const int *q_bad, const float *dk1, const float *q_eps, const float *q_scale,
+                              const float *q_norm, float gamma, int euclid, hipStream_t s);
 hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, uint32_t kp,
                               const int *only_flagged, hipStream_t s);
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s);

@@ -1567,6 +1567,76 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_select_kernel(const float *__
     }
 }
 
+// ---- second pass: every candidate above the safety margin, unsorted ----------------------------------------
+// A query that failed its first check because more than kp rows sit above the margin is decided again from a wider
+// candidate set.  What that set has to hold is every listed row whose score reaches the margin -- not the 256 BEST
+// scores in order (a 256-deep sorted select of ~16 000 candidates by ONE workgroup took 0.8 ms per flagged query:
+// a third of a 1024-query batch with one such query, 1.4 ms of every C4 batch).  The margin is known: the first
+// pass' k-th exact distance dk1 gives thr1, the wider pass can only find a smaller k-th distance, i.e. a higher
+// margin thr2 >= thr1, so {score >= thr1} contains everything the second check can call "above".  One workgroup per
+// flagged query filters the 3 n_lists scores against thr1 (the re-score kernels' own expressions) and compacts the
+// survivors into sel[q][0..256) in no particular order -- the exact re-score ranks by exact distance, and the list
+// rule counts entries per list: neither depends on the order.  More than 256 survivors: all slots are cleared, the
+// re-score finds fewer than k hits and leaves the query flagged for the exact scan.
+__global__ __launch_bounds__(256) void mfma_filter_kernel(const float *__restrict__ cand, uint64_t *__restrict__ sel,
+                                                          uint32_t n_lists, const int *__restrict__ flags,
+                                                          const int *__restrict__ q_bad, const float *__restrict__ dk1,
+                                                          const float *__restrict__ q_eps,
+                                                          const float *__restrict__ q_scale,
+                                                          const float *__restrict__ q_norm, float gamma, int euclid)
+{
+    const uint32_t q = blockIdx.x;
+    if (flags[q] == 0)
+        return;
+    __shared__ uint32_t s_n;
+    uint64_t *__restrict__ out = sel + (size_t)q * 256u;
+    out[threadIdx.x] = kSentinel;
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    if (q_bad[q]) // the path never ran for this query (zero / out-of-range norm): nothing to re-decide
+        return;
+    const float *__restrict__ src = cand + (size_t)q * kListDepth * n_lists;
+    const float ninf = __uint_as_float(0xff800000u);
+    const float dk = dk1[q];
+    const float thr = (1.0f - dk) - (q_eps[q] + 0x1p-13f);
+    const float qs = q_scale ? q_scale[q] : 1.0f;
+    const double a = (double)q_norm[q], g = (double)gamma;
+    const double vk_low = a * a * (1.0 - g) - (double)dk * (double)dk * (1.0 + g);
+    const uint32_t total = kListDepth * n_lists, lane = threadIdx.x & 63u;
+    for (uint32_t base = 0; base < total; base += 256u) { // (uniform trip count: the barrier-free loop has ballots)
+        const uint32_t i = base + threadIdx.x;
+        bool pass = false;
+        uint64_t comp = kSentinel;
+        if (i < total) {
+            const float sc = src[i];
+            if (sc != ninf) {
+                comp = ((uint64_t)dist_key(-sc) << 32) | (i % n_lists);
+                const float score = -key_dist((uint32_t)(comp >> 32)); // exactly what cand_row hands the re-score
+                if (euclid) {
+                    const double s2 = (double)score;
+                    pass = s2 + 0x1p-12 * (s2 < 0.0 ? -s2 : s2) >= vk_low;
+                } else {
+                    pass = (q_scale ? qs * score : score) >= thr;
+                }
+            }
+        }
+        const uint64_t mask = __ballot(pass);
+        if (mask) {
+            uint32_t pos0 = 0;
+            if (lane == 0)
+                pos0 = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+            pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos0);
+            const uint32_t my = pos0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && my < 256u)
+                out[my] = comp;
+        }
+    }
+    __syncthreads();
+    if (s_n > 256u) // does not fit: leave nothing, the re-score then keeps the query flagged
+        out[threadIdx.x] = kSentinel;
+}
+
 // ---- exact re-score + safety check ----------------------------------------------------------------
 // A candidate = (approximate score with the row position in its 10 low mantissa bits, list): the inverse of the
 // prefilter kernels' list / index assignment.
@@ -1587,7 +1657,7 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, const float *__restrict__ q_eps, uint64_t row_base,
     uint64_t id_base, uint32_t strip_tiles, const float *__restrict__ q_norm, float gamma, int only_flagged,
-    const float *__restrict__ q_scale)
+    const float *__restrict__ q_scale, float *__restrict__ dk_out)
 {
     if (only_flagged && flags[blockIdx.x] == 0) // second, wider pass: flagged queries only (uniform exit)
         return;
@@ -1705,6 +1775,8 @@ __global__ __launch_bounds__(kBlock) void mfma_rescore_kernel(
     // dist_r <= D_k, i.e. cos_ref(r) >= c_k = 1 - D_k, hence (|s~ - cos_ref| <= eps) s~_r >= c_k - eps, with
     // eps = eps_q + 2^-13: the 10 low mantissa bits of a score below 2 hold the row position.
     const float dk = s_dk;
+    if (dk_out && threadIdx.x == 0) // the wider second pass filters the candidate lists against this k-th distance
+        dk_out[q] = dk;
     bool bad = !(dk == dk) || !(dk < __uint_as_float(0x7f800000u)); // fewer than k exact hits / NaN
     bool above;
     if (METRIC == VFSX_EUCLIDEAN) {
@@ -1764,7 +1836,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void mfma_rescore_coop_kernel(
     const uint64_t *__restrict__ ids, vfsx_hit *__restrict__ out, int *__restrict__ flags, uint32_t n_rows,
     uint32_t d_chunks, uint32_t q_stride, uint32_t k, uint32_t kp, const float *__restrict__ q_eps, uint64_t row_base,
     uint64_t id_base, uint32_t strip_tiles, const float *__restrict__ q_norm, float gamma, int only_flagged,
-    const float *__restrict__ q_scale)
+    const float *__restrict__ q_scale, float *__restrict__ dk_out)
 {
     if (only_flagged && flags[blockIdx.x] == 0) // second, wider pass: flagged queries only (uniform exit)
         return;
@@ -1970,6 +2042,8 @@ __global__ __launch_bounds__(64 * kCoopWaves) void mfma_rescore_coop_kernel(
 
     // safety check: as in mfma_rescore_kernel, candidate ci in lane ci % cpw of wave ci / cpw
     const float dk = s_dk;
+    if (dk_out && threadIdx.x == 0) // the wider second pass filters the candidate lists against this k-th distance
+        dk_out[q] = dk;
     bool bad = !(dk == dk) || !(dk < __uint_as_float(0x7f800000u));
     bool above;
     if (METRIC == VFSX_EUCLIDEAN) {
@@ -2274,6 +2348,15 @@ hipError_t launch_mfma_select(const float *cand, uint64_t *sel, uint32_t nq, uin
     return hipGetLastError();
 }
 
+hipError_t launch_mfma_filter(const float *cand, uint64_t *sel, uint32_t nq, uint32_t n_lists, const int *flags,
+                              const int *q_bad, const float *dk1, const float *q_eps, const float *q_scale,
+                              const float *q_norm, float gamma, int euclid, hipStream_t s)
+{
+    hipLaunchKernelGGL(mfma_filter_kernel, dim3(nq), dim3(256), 0, s, cand, sel, n_lists, flags, q_bad, dk1, q_eps,
+                       q_scale, q_norm, gamma, euclid);
+    return hipGetLastError();
+}
+
 hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq, hipStream_t s)
 {
     const uint32_t list_stride = a.k > 64u ? 128u : 64u;
@@ -2284,14 +2367,14 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
                        a.row_norms,                                                                                  \
                        a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows, a.d_chunks, a.q_stride,     \
                        a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm, a.gamma, a.only_flagged,   \
-                       a.q_scale)
+                       a.q_scale, a.dk_out)
     // batches of <= 256 queries: the cooperative kernel (16 waves per query, lanes share the rows)
     const size_t lds_coop = (size_t)kCoopWaves * list_stride * sizeof(uint64_t);
 #define VFSX_RESCORE_C(DT, M, TOPK)                                                                                  \
     hipLaunchKernelGGL((mfma_rescore_coop_kernel<DT, M, TOPK>), dim3(nq), dim3(64 * kCoopWaves), lds_coop, s,        \
                        a.corpus, a.row_norms, a.queries, a.lut, a.sel, a.q_bad, a.ids, a.out, a.flags, a.n_rows,      \
                        a.d_chunks, a.q_stride, a.k, a.kp, a.q_eps, a.row_base, a.id_base, a.strip_tiles, a.q_norm,    \
-                       a.gamma, a.only_flagged, a.q_scale)
+                       a.gamma, a.only_flagged, a.q_scale, a.dk_out)
 #define VFSX_RESCORE(DT, M)                                                                                          \
     do {                                                                                                             \
         if (a.k <= kMaxRegisterK && coop)                                                                            \
@@ -2322,7 +2405,7 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     return hipGetLastError();
 }
 
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t skinny_cus)
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_cus, uint32_t n_qtiles)
 {
     MfmaGeometry g;
     // whole ring rounds only: K-steps (of 4 MFMA k-slices: 64 bf16 / 128 int8 k) per tile % ring depth (2) == 0, i.e.
@@ -2336,25 +2419,33 @@ MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t sk
     // one (small corpora get short strips -- and more workgroups); a list holds at most 1024 rows (10 index
     // bits): at most 16 tiles = 4096 rows per strip, 4 lists per strip
     g.strip_tiles = std::min<uint32_t>(kMaxStripTiles, std::max<uint32_t>(1u, (n_rows / 256u) * 4u / 4096u));
-    if (skinny_cus) {
-        // <= 128 queries (mfma_prefilter_skinny_kernel): one workgroup per strip and ONE workgroup per CU (its ring
-        // is 120 KiB), all strips the same length -- the launch takes ceil(strips / CUs) rounds of (strip_tiles tiles
-        // + about half a tile of ring fill and epilogue).  C2 (3907 tiles): 3 tiles per strip = 1303 workgroups =
-        // 5.09 -> 6 rounds = 18 tile times for 15.26 tiles of work per CU; 4 per strip = 3.82 -> 4 rounds = 16
-        // (measured 0.143 -> 0.128 ms, profiles/r03/c2m_strip_sweep.txt).  Pick the cheapest strip length that still
-        // leaves >= 2048 lists per query (the safety check flags a list with three rows above the margin: its
-        // rate grows with 1 / lists^2); ties go to the shorter strip.
-        uint32_t best = g.strip_tiles;
-        uint64_t best_cost = ~0ull;
-        for (uint32_t st = 1; st <= kMaxStripTiles; ++st) {
-            const uint32_t strips = (g.n_rowtiles + st - 1u) / st;
-            if (strips * 4u < 2048u && st > 1u)
-                break;
-            const uint64_t cost = (uint64_t)((strips + skinny_cus - 1u) / skinny_cus) * (2u * st + 1u);
-            if (cost < best_cost)
-                best_cost = cost, best = st;
+    if (n_cus) {
+        // Both prefilters run ONE workgroup per CU (their LDS rings are 120-128 KiB) and all strips have the same
+        // length, so a launch of W = query tiles x strips workgroups takes ceil(W / CUs) rounds of (strip_tiles tiles +
+        // about half a tile of ring fill and epilogue).  With few rounds the rounding matters: C2 (3907 tiles) and one
+        // query tile, 3 tiles per strip = 1303 workgroups = 5.09 -> 6 rounds = 18 tile times for 15.26 tiles of work
+        // per CU; 4 per strip = 3.82 -> 4 rounds = 16 (measured 0.143 -> 0.128 ms, profiles/r03/c2m_strip_sweep.txt).
+        // Pick the cheapest strip length that still leaves enough lists per query (the safety check flags a list
+        // with three rows above the margin: its rate grows with 1 / lists^2, and ONE flagged query costs its batch an
+        // exact scan, ~0.5 ms at this size): >= 2048 for one query tile, >= 3900 for more (measured: 2236 lists made
+        // one query per 1024-query batch fall back, 1.07 -> 1.68 ms, and 3908 lists still did: calls of more than two
+        // query tiles keep the size rule -- the more queries, the likelier one of them is flagged, and the less the
+        // rounding costs).  Ties go to the shorter strip.  Launches of >= 32 rounds keep the size rule as well.
+        const uint32_t strips0 = (g.n_rowtiles + g.strip_tiles - 1u) / g.strip_tiles;
+        if (n_qtiles <= 2u && (uint64_t)strips0 * n_qtiles < 32ull * n_cus) {
+            uint32_t best = g.strip_tiles;
+            uint64_t best_cost = ~0ull;
+            for (uint32_t st = 1; st <= kMaxStripTiles; ++st) {
+                const uint32_t strips = (g.n_rowtiles + st - 1u) / st;
+                if (strips * 4u < (n_qtiles == 1u ? 2048u : 3900u) && st > 1u)
+                    break;
+                const uint64_t wgs = (uint64_t)strips * n_qtiles;
+                const uint64_t cost = ((wgs + n_cus - 1u) / n_cus) * (2u * st + 1u);
+                if (cost < best_cost)
+                    best_cost = cost, best = st;
+            }
+            g.strip_tiles = best;
         }
-        g.strip_tiles = best;
     }
     static const uint32_t forced = std::getenv("VFSX_MFMA_STRIP") ? (uint32_t)std::atoi(std::getenv("VFSX_MFMA_STRIP")) : 0u;
     if (forced >= 1u && forced <= kMaxStripTiles) // experiments
