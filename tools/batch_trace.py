@@ -11,7 +11,7 @@ from vfs_amd import synth
 nq = int(sys.argv[1])
 K = int(os.environ.get("BT_K", "10"))
 quantize = len(sys.argv) > 2 and sys.argv[2] == "1"
-rows, dim = 1_000_000, 768
+rows, dim = int(os.environ.get("BT_ROWS", "1000000")), int(os.environ.get("BT_DIM", "768"))
 dev = torch.device("cuda:0")
 c = vfs_amd.Corpus(dim, quantize=quantize, capacity_rows=rows, device=0)
 c.fill_synthetic(synth.CORPUS_SEED, rows, row0=0, id0=1)
