@@ -350,7 +350,8 @@ struct vfsx_corpus {
     DeviceBuf<int> q_bad, q_flags;
     DeviceBuf<float> cand;
     DeviceBuf<uint64_t> sel;
-    std::vector<int> h_flags;
+    int *h_flags = nullptr; // pinned: the per-query flags of the matrix-core path, read once per call
+    size_t h_flags_cap = 0;
     uint64_t mfma_queries = 0, mfma_fallbacks = 0;
     // back-off: when most of a batch failed the bound check (near-duplicate-heavy data), the prefilter
     // was wasted work; skip it for the next `mfma_backoff` batches, doubling the pause while it keeps
@@ -981,7 +982,21 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     if (i8)
         c->q_scale.reserve(nq);
     c->q_flags.reserve(nq);
-    c->h_flags.assign(nq, 0);
+    if (nq > c->h_flags_cap) { // pinned, so that the read-back is one small asynchronous copy (no pageable staging)
+        if (c->h_flags)
+            (void)hipHostFree(c->h_flags);
+        c->h_flags = nullptr;
+        c->h_flags_cap = 0;
+        const size_t cap = std::max<size_t>(256, nq);
+        HIP_CHECK(hipHostMalloc((void **)&c->h_flags, cap * sizeof(int), hipHostMallocDefault));
+        c->h_flags_cap = cap;
+    }
+    std::memset(c->h_flags, 0, (size_t)nq * sizeof(int));
+    // Calls of a few queries (one round): the flags are read right after the first pass and the second pass is only
+    // launched when one of them is set -- almost never, so the usual call saves two launches (~10 us of 210 at C2
+    // size); a flagged call pays one more stream synchronisation.
+    const bool early_flags = nq <= 8u && kp < 256u;
+    bool flags_known = false;
 
     for (uint32_t q0 = 0; q0 < nq; q0 += q_round) {
         const uint32_t qn = std::min(q_round, nq - q0);
@@ -1034,7 +1049,16 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         // safety margin gets the widest candidate set the re-score kernel takes (256) and is decided
         // again; queries that passed exit at once.  (A list with three entries above the margin stays
         // flagged: only the exact scan can look inside it.)
-        if (kp < 256u) {
+        bool second_pass = kp < 256u;
+        if (early_flags) {
+            HIP_CHECK(hipMemcpyAsync(c->h_flags, c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            second_pass = false;
+            for (uint32_t q = 0; q < nq; ++q)
+                second_pass = second_pass || c->h_flags[q] != 0;
+            flags_known = !second_pass;
+        }
+        if (second_pass) {
             static const bool wide_select = std::getenv("VFSX_MFMA_WIDE") && std::getenv("VFSX_MFMA_WIDE")[0] == 's';
             if (wide_select) // (A/B: round 2's sorted 256-deep select)
                 HIP_CHECK(vfsx::launch_mfma_select(c->cand.p, c->sel.p, qn, g.n_lists, 256u, a.flags, s));
@@ -1047,8 +1071,10 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
             HIP_CHECK(vfsx::launch_mfma_rescore(c->dtype, a, qn, s));
         }
     }
-    HIP_CHECK(hipMemcpyAsync(c->h_flags.data(), c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    if (!flags_known) {
+        HIP_CHECK(hipMemcpyAsync(c->h_flags, c->q_flags.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
     c->mfma_queries += nq;
     {
         uint32_t flagged = 0;
@@ -1413,6 +1439,9 @@ void vfsx_corpus_destroy(vfsx_corpus *c)
     c->q_in.release();
     c->q_pad.release();
     c->hits.release();
+    if (c->h_flags)
+        (void)hipHostFree(c->h_flags);
+    c->h_flags = nullptr;
     if (c->h_call)
         (void)hipHostFree(c->h_call);
     c->h_call = c->d_call = nullptr;
