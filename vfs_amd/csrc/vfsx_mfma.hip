@@ -549,19 +549,26 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         advance();
     };
 
-    typename std::conditional<I8, i32x16, f32x16>::type acc[4][2];
+    using AccT = typename std::conditional<I8, i32x16, f32x16>::type;
+    // int8: the first k-slice of every tile multiplies into C = 0 and the epilogue leaves the accumulators as they
+    // are (c3b +4 %, c4i8 +0.5 %); bf16: the epilogue zeroes them as it reads them -- there the zeroing hides under
+    // the partner wave's MFMAs and the C = 0 form measured 0.8 % slower (profiles/r03/c4_analysis.md)
+    constexpr bool ZERO_C = I8;
+    AccT acc[4][2];
+    if (!ZERO_C) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[mi][ni][r] = 0;
+                for (int r = 0; r < 16; ++r)
+                    acc[mi][ni][r] = 0;
+    }
     const float ninf = __uint_as_float(0xff800000u);
     float m1[2] = {ninf, ninf}, m2[2] = {ninf, ninf}, m3[2] = {ninf, ninf};
     uint32_t keep_mask = ~kIdxMask;
     asm volatile("" : "+v"(keep_mask)); // keep it in a VGPR (see the epilogue)
-    uint32_t cur_kt = 0, cur_ts = 0;    // position of the running K-step inside the strip
+    uint32_t cur_kt = 0, cur_ts = 0;    // bf16 (flat loop): position of the running K-step inside the strip
     // MODE 1, per query column: bf16: cq = 2a, ce = eps_q;  int8: cq = 2a s_q (times S ||x|| inv_rn), ce = 2a eps_q (times ||x||)
     float cq[2] = {0.0f, 0.0f}, ce[2] = {0.0f, 0.0f};
     if (MODE == 1) {
@@ -631,10 +638,20 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
                         m3[ni] = __builtin_amdgcn_fmed3f(m2[ni], m3[ni], sp);
                         m2[ni] = __builtin_amdgcn_fmed3f(m1[ni], m2[ni], sp);
                         asm("v_max_f32 %0, %1, %2" : "=v"(m1[ni]) : "v"(m1[ni]), "v"(sp));
-                        acc[mi][ni][r] = 0;
+                        if (!ZERO_C) // (int8: not reset, the next tile's first k-slice multiplies into C = 0)
+                            acc[mi][ni][r] = 0;
                     }
                 }
             }
+    };
+    // tile finished: fold its 128 scores per lane into the running top-3 of each query column.
+    // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    auto fold_one_tile = [&](uint32_t ts) __attribute__((always_inline)) {
+        const uint32_t tile_row0 = (tile0 + ts) * TROWS;
+        if (tile_row0 + TROWS > n_rows)
+            fold_tile(std::true_type{}, ts, tile_row0); // last, ragged tile: rows >= n_rows masked
+        else
+            fold_tile(std::false_type{}, ts, tile_row0);
     };
 
 #ifdef VFSX_EXP_STAMPS
@@ -659,8 +676,12 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         for (uint32_t ni = 0; ni < 2; ++ni)
             fb[set][ni] = rd[(A_UNITS + (wave_n * 2u + ni) * KU + ks) * 64u + lane];
     };
-    auto kstep = [&](auto jc, uint32_t it) {
+    // FIRST: the tile's first K-step -- its first k-slice multiplies into C = 0 (an inline constant of the MFMA),
+    // so the epilogue does not have to zero the 128 accumulator registers it has just read (one VALU operation per
+    // element less: a seventh of the int8 fold, a fifth of the bf16 one)
+    auto kstep = [&](auto jc, auto first_c) {
         constexpr int J = decltype(jc)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
         constexpr int JW = (J + NSTAGE - 1) % NSTAGE;
         constexpr int JN = (J + 1) % NSTAGE;
         const uint4 *rd = slot(J);
@@ -706,27 +727,27 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = mfma_32x32(fa[set][mi], fb[set][ni], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (ZERO_C && FIRST && ks == 0u)
+                        acc[mi][ni] = mfma_32x32(fa[set][mi], fb[set][ni], AccT{});
+                    else
+                        acc[mi][ni] = mfma_32x32(fa[set][mi], fb[set][ni], acc[mi][ni]);
+                }
         }
         VFSX_STAMP(t3);
 #ifdef VFSX_EXP_STAMPS
         st_vm += t1 - t0, st_bar += t2 - t1, st_body += t3 - t2, st_n += 1;
 #endif
-        if (++cur_kt == KT) {
-            // tile finished: fold its 128 scores per lane into the running top-3 of each query column.
-            // C/D layout: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-            const uint32_t ts = cur_ts;
-            cur_kt = 0;
-            ++cur_ts;
-            const uint32_t tile_row0 = (tile0 + ts) * TROWS;
-            if (tile_row0 + TROWS > n_rows)
-                fold_tile(std::true_type{}, ts, tile_row0); // last, ragged tile: rows >= n_rows masked
-            else
-                fold_tile(std::false_type{}, ts, tile_row0);
+        if (!ZERO_C) { // bf16: the fold sits behind the tile's last K-step, inside the flat loop (see the main loop)
+            if (++cur_kt == KT) {
+                const uint32_t ts = cur_ts;
+                cur_kt = 0;
+                ++cur_ts;
+                fold_one_tile(ts);
 #ifdef VFSX_EXP_STAMPS
-            st_fold += __builtin_amdgcn_s_memtime() - t3;
+                st_fold += __builtin_amdgcn_s_memtime() - t3;
 #endif
+            }
         }
     };
 
@@ -746,14 +767,42 @@ __global__ __launch_bounds__(512) void mfma_prefilter256_kernel(const uint4 *__r
         asm volatile("" ::: "memory");
         load_frags(lds_s0, 0u, 0);
     }
-    // n_it % NSTAGE == 0 (the host pads K so that KT is a multiple of NSTAGE): a straight-line round
-    for (uint32_t it = 0; it < n_it; it += NSTAGE) {
-        kstep(std::integral_constant<int, 0>{}, it);
-        kstep(std::integral_constant<int, 1>{}, it + 1);
-        if (NSTAGE > 2)
-            kstep(std::integral_constant<int, (NSTAGE > 2 ? 2 : 0)>{}, it + 2);
-        if (NSTAGE > 3)
-            kstep(std::integral_constant<int, (NSTAGE > 3 ? 3 : 0)>{}, it + 3);
+    // KT % NSTAGE == 0 (the host pads K so that KT is a multiple of NSTAGE): every tile starts on ring slot 0 and is
+    // a whole number of straight-line rounds.
+    if (ZERO_C) {
+        // int8: tile by tile, the tile's first K-step is its own instantiation (C = 0), the fold follows the last
+        for (uint32_t ts = 0; ts < ntiles; ++ts) {
+            kstep(std::integral_constant<int, 0>{}, std::true_type{}); // (peeled: no branch inside the rounds below)
+            kstep(std::integral_constant<int, 1>{}, std::false_type{});
+            if (NSTAGE > 2)
+                kstep(std::integral_constant<int, (NSTAGE > 2 ? 2 : 0)>{}, std::false_type{});
+            if (NSTAGE > 3)
+                kstep(std::integral_constant<int, (NSTAGE > 3 ? 3 : 0)>{}, std::false_type{});
+            for (uint32_t kt = NSTAGE; kt < KT; kt += NSTAGE) {
+                kstep(std::integral_constant<int, 0>{}, std::false_type{});
+                kstep(std::integral_constant<int, 1>{}, std::false_type{});
+                if (NSTAGE > 2)
+                    kstep(std::integral_constant<int, (NSTAGE > 2 ? 2 : 0)>{}, std::false_type{});
+                if (NSTAGE > 3)
+                    kstep(std::integral_constant<int, (NSTAGE > 3 ? 3 : 0)>{}, std::false_type{});
+            }
+            VFSX_STAMP(tf0);
+            fold_one_tile(ts);
+#ifdef VFSX_EXP_STAMPS
+            st_fold += __builtin_amdgcn_s_memtime() - tf0;
+#endif
+        }
+    } else {
+        // bf16: one flat loop over the strip's K-steps, the fold inside the K-step that ends a tile -- the
+        // tile-structured form above measured 1-1.6 % slower here (profiles/r03/c4_analysis.md)
+        for (uint32_t it = 0; it < n_it; it += NSTAGE) {
+            kstep(std::integral_constant<int, 0>{}, std::false_type{});
+            kstep(std::integral_constant<int, 1>{}, std::false_type{});
+            if (NSTAGE > 2)
+                kstep(std::integral_constant<int, (NSTAGE > 2 ? 2 : 0)>{}, std::false_type{});
+            if (NSTAGE > 3)
+                kstep(std::integral_constant<int, (NSTAGE > 3 ? 3 : 0)>{}, std::false_type{});
+        }
     }
 
     // the redundant tail stages are still in flight: they must land before this workgroup's LDS is released
