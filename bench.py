@@ -456,7 +456,7 @@ def main(argv=None) -> int:
 
     # Side leg (not `value`): the same single-query steps with the opt-in int8 mirror switched on -- the prefilter
     # reads 1 B per element where the scan above reads 4, the hits are the same bits (checked here on one step).
-    if (args.mode == "single" and not quantize and not mirror_single and not mfma and rows * dim >= 250_000_000
+    if (args.mode == "single" and not quantize and not mirror_single and not mfma and rows * dim >= 175_000_000
             and k <= 32 and metric in (0, 1, 2, 3) and not os.environ.get("VFSX_BENCH_NO_MIRROR_LEG")
             and (world == 1 or os.environ.get("VFSX_BENCH_MIRROR_LEG"))):  # N > 1: only on request (rehearsals)
         try:

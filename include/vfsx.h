@@ -407,7 +407,7 @@ int vfsx_comm_merge_hits(vfsx_comm *comm, const vfsx_hit *d_local, uint32_t nq, 
  * and moves to bf16 for good when the rows' measured quantization residual is large or more than 1/8 of the queries
  * (counted over windows of >= 64) come back.  An int8 store needs no mirror: its rb64 rows are the int8 operand (+12 bytes per row).
  * Afterwards vfsx_search / vfsx_search_device route Cosine and Euclidean (and Simd*) batches of >= 4 queries -- on an
- * f32 store of >= 2.5e8 elements (4e8 with the bf16 mirror) every call with k <= 32, single queries included (while such
+ * f32 store of >= 1.75e8 elements (3e8 with the bf16 mirror) every call with k <= 32, single queries included (while such
  * calls mostly pass the check): the prefilter reads
  * the mirror's 1 or 2 bytes per element where the exact scan reads 4 (VFSX_MFMA_MIN_BATCH overrides) -- with
  * k <= 128 on corpora of >= 16384 rows whose row norms all lie in [2^-30, 2^30] (queries outside that range take the

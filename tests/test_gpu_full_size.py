@@ -155,7 +155,7 @@ def test_c4_10m_x1024_mfma_batch_equals_exact_scan(oracle):
 
 
 def test_c2_single_queries_through_the_mirror_equal_exact_scan(oracle):
-    """C2 size, f32 store with the (opt-in) mirror: from 2.5e8 elements on even ONE query per call goes through the
+    """C2 size, f32 store with the (opt-in) mirror: from 1.75e8 elements on even ONE query per call goes through the
     matrix-core path (the prefilter reads the 1 B per element mirror, the scan 4 B per element; vfsx_api.cpp
     mfma_min_batch_for).  Every such query must equal the exact scan bit for bit, for both mirrors, Cosine and
     Euclidean, k = 10 and 100; a small corpus keeps single queries on the exact scan."""

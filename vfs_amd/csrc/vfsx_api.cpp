@@ -1170,8 +1170,9 @@ void chain_search_stream(vfsx_corpus *c, hipStream_t s)
 // shape measured.  Below that the exact scan shares one pass among the queries -- but on an f32 store the prefilter
 // reads the MIRROR, 1 B (int8) or 2 B (bf16) per element where the scan reads 4: once the bytes saved outweigh the
 // path's fixed ~120 us (launch chain, re-score gather, flag read-back) even a single query is faster through it
-// (1M x 768: 0.243 vs 0.449 ms; 12.5M x 768: 1.56 vs 5.48 ms) -- from 2.5e8 elements on with the int8 mirror, 4e8 with
-// the bf16 one (profiles/r02/single_query_crossover.txt).  VFSX_MFMA_MIN_BATCH overrides.
+// (1M x 768: 0.201 vs 0.449 ms; 12.5M x 768: 1.51 vs 5.47 ms) -- from 1.75e8 elements on with the int8 mirror, 3e8 with
+// the bf16 one (profiles/r03/single_query_crossover.txt: round 3's shorter chain moved both down from 2.5e8 / 4e8).
+// VFSX_MFMA_MIN_BATCH overrides.
 // Only for k <= 32 (at k = 100 on random 768-d rows most single queries fail the check: 1M x 768 2150 q/s exact,
 // 870 through the path), and only while such calls mostly pass: a window of 64 of them with more than a quarter
 // flagged keeps the next 8192 on the exact scan (then the path is probed again).
@@ -1181,7 +1182,7 @@ uint32_t mfma_min_batch_for(const vfsx_corpus *c, uint32_t k)
         return c->mfma_min_batch;
     if (c->dtype == VFSX_F32 && k <= 32u && c->small_off == 0u) {
         const uint64_t elems = c->n_rows * (uint64_t)c->dim;
-        if (elems >= (mirror_is_i8(c) ? 250000000ull : 400000000ull))
+        if (elems >= (mirror_is_i8(c) ? 175000000ull : 300000000ull))
             return 1;
     }
     return 4;

@@ -118,7 +118,7 @@ def err_body(msg: str) -> str:
 
 def _new_corpus(dim: int, quantize: bool, device: int):
     """The resident store.  VFSX_SERVER_MIRROR=1 switches the matrix-core path on (no reference counterpart; results
-    unchanged): /search on an f32 store of >= 2.5e8 elements with ef_search <= 32 is then pre-filtered from the 1 B per
+    unchanged): /search on an f32 store of >= 1.75e8 elements with ef_search <= 32 is then pre-filtered from the 1 B per
     element int8 mirror instead of scanning 4 B per element; inserts extend the mirror (vfsx_api.cpp ensure_mirror)."""
     import vfs_amd
     corpus = vfs_amd.Corpus(dim, quantize=quantize, device=device)
