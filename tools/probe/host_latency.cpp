@@ -59,6 +59,17 @@ static void run(uint64_t n, uint32_t d, int dtype, int metric, int iters)
         t[i] = now_us() - t0;
     }
     std::sort(t.begin(), t.end());
+    // device buffers, launches pipelined (one synchronisation at the end): what bench.py's `value` measures, without
+    // the Python / ctypes overhead per call
+    (void)hipStreamSynchronize(s);
+    const double p0 = now_us();
+    for (int i = 0; i < iters; ++i)
+        vfsx_search_device(c, d_q + (size_t)(i % 64) * d, 1, k, metric, d_h, s);
+    const double p_issue = now_us() - p0;
+    (void)hipStreamSynchronize(s);
+    const double p_all = now_us() - p0;
+    std::printf("          pipelined: %.2f us per query (%.0f q/s), host side %.2f us per call\n", p_all / iters,
+                iters / p_all * 1e6, p_issue / iters);
     std::printf("%9llu x %4u %s metric %d: host buffers median %.1f us (p99 %.1f), device buffers + sync median %.1f us (p99 %.1f); "
                 "first hit id %llu\n",
                 (unsigned long long)n, d, dtype ? "int8" : "f32", metric, host_med, host_p99, t[iters / 2],
