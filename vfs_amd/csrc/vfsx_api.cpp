@@ -944,7 +944,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
     const bool i8 = prefilter_is_i8(c);
     // (query tiles per prefilter launch: a call of more queries than one round holds runs several launches of
     // q_round; the geometry is the first one's, the others are at least as large)
-    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8, c->n_cus, (nq + 255u) / 256u);
+    const vfsx::MfmaGeometry g = vfsx::mfma_geometry((uint32_t)c->n_rows, c->dim, i8, c->n_cus, nq);
     const size_t qm_elem = i8 ? 1u : 2u; // query mirror: int8 or bf16
     // the int8 prefilter's row operand: the int8 store itself, or the int8 mirror of an f32 store
     const uint4 *a_rows = mirror_is_i8(c) ? c->d_mirror : c->d_corpus;
@@ -1039,7 +1039,7 @@ void mfma_search_device(vfsx_corpus *c, const float *d_queries, uint32_t nq, uin
         a.q_scale = i8 ? c->q_scale.p + q0 : nullptr;
         a.row_base = c->row_base;
         a.id_base = c->id_base;
-        a.strip_tiles = g.strip_tiles;
+        a.strip_tiles = g.strip_code(); // (tiles per strip | kStripOwnLists: how a candidate's list decodes)
         a.euclid = euclid;
         a.q_norm = c->q_norm.p + q0;
         a.gamma = mfma_gamma(g.k_pad);

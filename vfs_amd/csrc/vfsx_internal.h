@@ -109,6 +109,7 @@ hipError_t launch_query_quantize(const float *d_queries, uint32_t nq, uint32_t d
 hipError_t launch_scan_i8dom(const ScanArgs &a, uint32_t nq, uint32_t grid_x, bool nt, float scale, hipStream_t s);
 
 // ---- many-query batches on the matrix cores (vfsx_mfma.hip) ---------------------------------
+constexpr uint32_t kStripOwnLists = 0x100u; // flag on a kernel's strip_tiles argument: 16 lists per strip
 struct MfmaGeometry {
     uint32_t k_pad;      // dim rounded up to 128
     uint32_t KS;         // fragment k-slices: k_pad / 16 (bf16) or k_pad / 32 (int8)
@@ -116,7 +117,12 @@ struct MfmaGeometry {
     uint32_t n_rowtiles; // ceil(n_rows / 256)
     uint32_t strip_tiles; // row tiles per strip (1..16)
     uint32_t n_strips;   // ceil(n_rowtiles / strip_tiles)
-    uint32_t n_lists;    // candidate lists per query = 4 * n_strips
+    uint32_t strip_lists; // candidate lists per strip and query: 4 (the four waves of a 128-row half merged), or 16
+                          // (small-batch kernel, long strips: every wave keeps its own two lists -- same rows per
+                          // list as four merged waves of a strip a quarter as long)
+    uint32_t n_lists;    // candidate lists per query = strip_lists * n_strips
+    // what the kernels that decode a candidate (and the small-batch prefilter) receive as `strip_tiles`
+    uint32_t strip_code() const { return strip_tiles | (strip_lists == 16u ? kStripOwnLists : 0u); }
     size_t mirror_bytes; // bf16 mirror of the corpus (rows padded to 256); 0 for int8 stores (rb64 is the operand)
 };
 constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor assumes K <= 32768
@@ -124,9 +130,10 @@ constexpr uint32_t kMfmaMaxDim = 32768; // the error model's (1 + 2^-7) factor a
 // up to the 2^32 - 66 the exact scan serves, keep the exact scan)
 constexpr uint64_t kMfmaMaxRows = 0xfffffe00ull;
 constexpr uint32_t kMfmaMaxK = 128; // result_limit the matrix-core batch path serves (256 candidates re-scored per query)
-// n_cus != 0: the geometry of ONE prefilter launch over n_qtiles query tiles (1 for <= 128 queries: the small-batch
-// kernel) on a device with that many CUs -- the strip length is then chosen for whole rounds of workgroups
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_cus = 0, uint32_t n_qtiles = 1);
+// n_cus != 0: the geometry of ONE prefilter launch of nq queries on a device with that many CUs -- the strip length
+// (and, for the small-batch kernel, the lists per strip) is then chosen for whole rounds of workgroups
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_cus = 0, uint32_t nq = 256);
+bool mfma_small_batch(uint32_t nq); // does a launch of nq queries take mfma_prefilter_skinny_kernel?
 float mfma_f32_slack(uint32_t k_pad);
 
 struct MfmaRescoreArgs {

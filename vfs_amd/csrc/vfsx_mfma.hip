@@ -1284,6 +1284,8 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // SGPR
     const uint32_t wave_m = wave >> 2, mi = wave & 3u;
     const uint32_t strip = blockIdx.x;
+    const bool own_lists = (strip_tiles & kStripOwnLists) != 0u; // 16 lists per strip: no merge of the four waves
+    strip_tiles &= 0xffu;
     const uint32_t tile0 = strip * strip_tiles;
     const uint32_t ntiles = min(strip_tiles, n_rowtiles - tile0);
     const uint32_t KT = KS / KU;
@@ -1497,6 +1499,19 @@ __global__ __launch_bounds__(512) void mfma_prefilter_skinny_kernel(const uint4 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if (own_lists) { // long strips: list = (strip, wave, 16-row half), 16 rows per tile each -- nothing to merge
+        const uint32_t list = strip * 16u + wave * 2u + (lane >> 5);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const uint32_t q = (uint32_t)ni * 32u + (lane & 31u);
+            if (q < nq) {
+                cand[((size_t)q * kListDepth + 0u) * n_lists + list] = m1[ni];
+                cand[((size_t)q * kListDepth + 1u) * n_lists + list] = m2[ni];
+                cand[((size_t)q * kListDepth + 2u) * n_lists + list] = m3[ni];
+            }
+        }
+        return;
+    }
     // merge the four waves of one wave_m: [wave][ni][3][64] floats in the (now idle) ring
     float *xch = (float *)ring;
 #pragma unroll
@@ -1695,8 +1710,10 @@ __device__ __forceinline__ uint32_t cand_row(uint64_t comp, float &score, uint32
     score = -key_dist((uint32_t)(comp >> 32));
     const uint32_t idx = __float_as_uint(score) & kIdxMask;
     const uint32_t ts = idx >> 6, mi = (idx >> 4) & 3u, r = idx & 15u;
-    const uint32_t strip = list >> 2, wave_m = (list >> 1) & 1u, half = list & 1u;
-    return (strip * strip_tiles + ts) * 256u + wave_m * 128u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
+    // 4 lists per strip: (wave_m, half); 16 (kStripOwnLists): (wave = 4 wave_m + mi, half) -- mi is in the index either way
+    const bool own = (strip_tiles & kStripOwnLists) != 0u;
+    const uint32_t strip = own ? list >> 4 : list >> 2, wave_m = own ? (list >> 3) & 1u : (list >> 1) & 1u, half = list & 1u;
+    return (strip * (strip_tiles & 0xffu) + ts) * 256u + wave_m * 128u + mi * 32u + (r & 3u) + 8u * (r >> 2) + 4u * half;
 }
 
 template <int DTYPE, int METRIC, typename TopK>
@@ -2248,8 +2265,7 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
     const uint4 *qm = (const uint4 *)q_mirror;
     const float2 *rn = (const float2 *)rn2;
     // <= 128 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
-    static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
-    if (skinny_on && nq <= 128u) {
+    if (mfma_small_batch(nq)) {
         // rows larger than what the Infinity Cache keeps between batches are streamed nontemporally (as the exact scan)
         const bool nt = (uint64_t)g.n_rowtiles * 256u * g.k_pad * 2u > (192ull << 20);
 #define VFSX_SKINNY(MODE, NCOL)                                                                                    \
@@ -2257,12 +2273,12 @@ hipError_t launch_mfma_prefilter(const uint4 *mirror, const void *q_mirror, floa
         if (nt)                                                                                                    \
             hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, false, true>), dim3(g.n_strips),       \
                                dim3(512), 0, s, mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists,       \
-                               g.strip_tiles, rn, q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr,          \
+                               g.strip_code(), rn, q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr,          \
                                (const float *)nullptr);                                                            \
         else                                                                                                       \
             hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, false, false>), dim3(g.n_strips),      \
                                dim3(512), 0, s, mirror, qm, cand, n_rows, g.n_rowtiles, g.KS, nq, g.n_lists,       \
-                               g.strip_tiles, rn, q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr,          \
+                               g.strip_code(), rn, q_norm, q_eps, 0u, (uint64_t)0, (const float *)nullptr,          \
                                (const float *)nullptr);                                                            \
     } while (0)
         if (nq <= 64u) {
@@ -2314,20 +2330,19 @@ hipError_t launch_mfma_prefilter_i8(const uint4 *corpus, uint32_t d_chunks, uint
     const uint32_t n_qtiles = (nq + 255u) / 256u;
     uint32_t qpx = 1;
     const dim3 grid = pf_grid(g, n_qtiles, (size_t)256u * g.k_pad, &qpx);
-    static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
-    if (skinny_on && nq <= 128u) {
+    if (mfma_small_batch(nq)) {
         const bool nt = (uint64_t)g.n_rowtiles * 256u * g.k_pad > (192ull << 20); // (as above; 1 B per element)
 #define VFSX_SKINNY(MODE, NCOL)                                                                                    \
     do {                                                                                                           \
         if (nt)                                                                                                    \
             hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, true, true>), dim3(g.n_strips),        \
                                dim3(512), 0, s, corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, \
-                               nq, g.n_lists, g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks,         \
+                               nq, g.n_lists, g.strip_code(), (const float2 *)rn2, q_norm, q_eps, d_chunks,         \
                                corpus_bytes, inv_rn, q_scale);                                                     \
         else                                                                                                       \
             hipLaunchKernelGGL((mfma_prefilter_skinny_kernel<3, MODE, NCOL, true, false>), dim3(g.n_strips),       \
                                dim3(512), 0, s, corpus, (const uint4 *)q_mirror, cand, n_rows, g.n_rowtiles, g.KS, \
-                               nq, g.n_lists, g.strip_tiles, (const float2 *)rn2, q_norm, q_eps, d_chunks,         \
+                               nq, g.n_lists, g.strip_code(), (const float2 *)rn2, q_norm, q_eps, d_chunks,         \
                                corpus_bytes, inv_rn, q_scale);                                                     \
     } while (0)
         if (nq <= 64u) {
@@ -2454,9 +2469,19 @@ hipError_t launch_mfma_rescore(int dtype, const MfmaRescoreArgs &a, uint32_t nq,
     return hipGetLastError();
 }
 
-MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_cus, uint32_t n_qtiles)
+// <= 128 queries: the skinny kernel (HBM-bound instead of latency-bound); VFSX_MFMA_SKINNY=0 turns it off
+bool mfma_small_batch(uint32_t nq)
+{
+    static const bool skinny_on = !(std::getenv("VFSX_MFMA_SKINNY") && std::getenv("VFSX_MFMA_SKINNY")[0] == '0');
+    return skinny_on && nq <= 128u;
+}
+
+MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_cus, uint32_t nq)
 {
     MfmaGeometry g;
+    const uint32_t n_qtiles = (nq + 255u) / 256u;
+    const bool small = mfma_small_batch(nq);
+    g.strip_lists = 4u;
     // whole ring rounds only: K-steps (of 4 MFMA k-slices: 64 bf16 / 128 int8 k) per tile % ring depth (2) == 0, i.e.
     // K a multiple of 128 (bf16) or 256 (int8); the int8 kernel also exists with K-steps of 2 k-slices (ku = 2), which
     // takes the multiples of 128 in between
@@ -2480,27 +2505,40 @@ MfmaGeometry mfma_geometry(uint32_t n_rows, uint32_t dim, bool int8, uint32_t n_
         // one query per 1024-query batch fall back, 1.07 -> 1.68 ms, and 3908 lists still did: calls of more than two
         // query tiles keep the size rule -- the more queries, the likelier one of them is flagged, and the less the
         // rounding costs).  Ties go to the shorter strip.  Launches of >= 32 rounds keep the size rule as well.
+        // The small-batch kernel has a second form for long strips (strip_lists = 16): every wave keeps its own two
+        // lists instead of merging with the three other waves of its 128-row half, so a 16-tile strip yields the lists
+        // (and rows per list) of four 4-tile strips -- one workgroup per CU for the whole launch, one ring fill and
+        // epilogue instead of four (C2: 245 workgroups, 1 round x 16 tiles; <= 8192 lists so that the select stays
+        // short).
         const uint32_t strips0 = (g.n_rowtiles + g.strip_tiles - 1u) / g.strip_tiles;
         if (n_qtiles <= 2u && (uint64_t)strips0 * n_qtiles < 32ull * n_cus) {
-            uint32_t best = g.strip_tiles;
+            static const bool own_ok = !(std::getenv("VFSX_MFMA_OWN_LISTS") && std::getenv("VFSX_MFMA_OWN_LISTS")[0] == '0');
+            uint32_t best = g.strip_tiles, best_lists = 4u;
             uint64_t best_cost = ~0ull;
-            for (uint32_t st = 1; st <= kMaxStripTiles; ++st) {
-                const uint32_t strips = (g.n_rowtiles + st - 1u) / st;
-                if (strips * 4u < (n_qtiles == 1u ? 2048u : 3900u) && st > 1u)
-                    break;
-                const uint64_t wgs = (uint64_t)strips * n_qtiles;
-                const uint64_t cost = ((wgs + n_cus - 1u) / n_cus) * (2u * st + 1u);
-                if (cost < best_cost)
-                    best_cost = cost, best = st;
+            for (uint32_t lists = 4u; lists <= ((small && own_ok) ? 16u : 4u); lists *= 4u) {
+                for (uint32_t st = 1; st <= kMaxStripTiles; ++st) {
+                    const uint32_t strips = (g.n_rowtiles + st - 1u) / st;
+                    if (strips * lists < (n_qtiles == 1u ? 2048u : 3900u) && st > 1u)
+                        break;
+                    if (lists == 16u && strips * lists > 8192u)
+                        continue;
+                    const uint64_t wgs = (uint64_t)strips * n_qtiles;
+                    const uint64_t cost = ((wgs + n_cus - 1u) / n_cus) * (2u * st + 1u);
+                    if (cost < best_cost)
+                        best_cost = cost, best = st, best_lists = lists;
+                }
             }
             g.strip_tiles = best;
+            g.strip_lists = best_lists;
         }
     }
     static const uint32_t forced = std::getenv("VFSX_MFMA_STRIP") ? (uint32_t)std::atoi(std::getenv("VFSX_MFMA_STRIP")) : 0u;
-    if (forced >= 1u && forced <= kMaxStripTiles) // experiments
+    if (forced >= 1u && forced <= kMaxStripTiles) { // experiments (always the merged, 4-lists form)
         g.strip_tiles = forced;
+        g.strip_lists = 4u;
+    }
     g.n_strips = (g.n_rowtiles + g.strip_tiles - 1) / g.strip_tiles;
-    g.n_lists = g.n_strips * 4u;
+    g.n_lists = g.n_strips * g.strip_lists;
     g.mirror_bytes = int8 ? 0 : (size_t)g.n_rowtiles * 256u * g.k_pad * 2u; // int8 stores need no mirror
     return g;
 }
